@@ -1,0 +1,80 @@
+"""ctypes binding of ``lib/libanemoi_graphs_hip.so`` (declared in ``include/anemoi_graphs_hip.h``).
+
+The library is mandatory: there is no CPU or PyTorch fallback for any operation of this package.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libanemoi_graphs_hip.so"
+
+_P = c_void_p  # every device pointer and the stream travel as void*
+
+# name -> (restype, argtypes); mirrors include/anemoi_graphs_hip.h one to one
+SIGNATURES = {
+    "ag_last_error": (c_char_p, []),
+    "ag_version": (c_int, []),
+    "ag_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_nn_maxdist_workspace_bytes": (c_size_t, [c_int64]),
+    "ag_nn_maxdist": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
+    "ag_radius_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ag_radius_count": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, _P, c_size_t, _P]),
+    "ag_radius_fill": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_icosphere_sizes": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "ag_icosphere_workspace_bytes": (c_size_t, [c_int]),
+    "ag_icosphere": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_multiscale_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ag_multiscale_count": (c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_multiscale_fill": (
+        c_int,
+        [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, _P, _P, c_int64, _P, _P, _P, c_size_t, _P],
+    ),
+    "ag_edge_attrs": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P]),
+    "ag_normalise_workspace_bytes": (c_size_t, [c_int64]),
+    "ag_normalise": (c_int, [_P, c_int64, c_int, c_int, _P, c_size_t, _P]),
+    "ag_sort_edges_workspace_bytes": (c_size_t, [c_int64]),
+    "ag_sort_edges": (c_int, [_P, _P, c_int64, c_int, _P, c_size_t, _P]),
+    "ag_unique_edges": (c_int, [_P, _P, c_int64, _P, _P, c_size_t, _P]),
+    "ag_mask_compact_workspace_bytes": (c_size_t, [c_int64]),
+    "ag_mask_compact": (c_int, [_P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "ag_gather_coords": (c_int, [_P, _P, c_int64, _P, _P]),
+    "ag_remap_ids": (c_int, [_P, c_int64, _P, _P]),
+}
+
+
+class LibraryError(RuntimeError):
+    """An entry point of libanemoi_graphs_hip.so reported failure."""
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises if it has not been built: no fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m anemoi_graphs_amd.build` "
+            "(hipcc, gfx950).  This package has no CPU or PyTorch fallback."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:  # TEMPORARY while the library is being brought up
+            continue
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().ag_last_error()
+        raise LibraryError(f"{what} failed ({status}): {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,200 @@
+// Shared host/device helpers of libanemoi_graphs_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/anemoi_graphs_hip.h"
+
+#define AG_PI 3.14159265358979323846
+#define AG_TWO_PI 6.28318530717958647692
+#define AG_HALF_PI 1.57079632679489661923
+#define AG_INV_TWO_PI 0.15915494309189533577
+
+// ---------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------
+std::string& ag_error_slot();
+int ag_fail(int code, const char* fmt, ...);
+
+#define AG_HIP(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e__ = (call);                                                                          \
+    if (e__ != hipSuccess) return ag_fail(AG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+#define AG_REQUIRE(cond, ...)                            \
+  do {                                                   \
+    if (!(cond)) return ag_fail(AG_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+#define AG_LAUNCH_CHECK() AG_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// workspace carving: the same code sizes the workspace (base == nullptr) and hands out pointers
+// ---------------------------------------------------------------------------------------------
+struct AgCarver {
+  char* base;
+  size_t used = 0;
+  explicit AgCarver(void* p) : base(static_cast<char*>(p)) {}
+  template <class T>
+  T* take(size_t count) {
+    used = (used + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+    used += count * sizeof(T);
+    return p;
+  }
+  size_t total() const { return (used + 255) & ~size_t(255); }
+};
+
+static inline int ag_blocks(int64_t n, int per_block, int64_t cap = (1 << 30)) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return static_cast<int>(b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the binning grid: latitude bands of equal height, each cut into an integer number of
+// longitude cells of roughly the band height (in great-circle terms); the polar bands
+// degenerate to one cell.  Cells are numbered band-major, so the cells of one band that cover a
+// longitude interval are consecutive and their points are consecutive in the binned array.
+// ---------------------------------------------------------------------------------------------
+struct AgGrid {
+  int nb;             // number of latitude bands
+  double dlat;        // pi / nb
+  double inv_dlat;    // nb / pi
+  const int* ncols;   // [nb]    cells in band b           (device)
+  const int* off;     // [nb+1]  first cell id of band b   (device); off[nb] = number of cells
+};
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ double ag_wrap_lon(double lon) {
+  double t = lon - AG_TWO_PI * floor(lon * AG_INV_TWO_PI);
+  if (t < 0.0) t += AG_TWO_PI;
+  if (t >= AG_TWO_PI) t -= AG_TWO_PI;
+  if (t < 0.0) t = 0.0;
+  return t;
+}
+
+__device__ __forceinline__ int ag_band_of(const AgGrid& g, double lat) {
+  int b = static_cast<int>(floor((AG_HALF_PI - lat) * g.inv_dlat));
+  return min(max(b, 0), g.nb - 1);
+}
+
+__device__ __forceinline__ int ag_cell_of(const AgGrid& g, double lat, double lon) {
+  const int b = ag_band_of(g, lat);
+  const int nc = g.ncols[b];
+  int c = static_cast<int>(ag_wrap_lon(lon) * (nc * AG_INV_TWO_PI));
+  c = min(max(c, 0), nc - 1);
+  return g.off[b] + c;
+}
+
+// The float64 "reduced distance" scikit-learn ranks by (sklearn/metrics/_dist_metrics.pyx.tp,
+// HaversineDistance.rdist): separate roundings, no fused multiply-add (built with -ffp-contract=off).
+__device__ __forceinline__ double ag_rdist(double lat1, double lon1, double lat2, double lon2) {
+  const double s0 = sin(0.5 * (lat1 - lat2));
+  const double s1 = sin(0.5 * (lon1 - lon2));
+  return (s0 * s0 + cos(lat1) * cos(lat2) * s1 * s1);
+}
+
+__device__ __forceinline__ double ag_rdist_to_dist(double r) { return 2.0 * asin(sqrt(r)); }
+
+// float32 unit vector of a (lat, lon) point, rounded from float64
+__device__ __forceinline__ float3 ag_unit_vec(float lat, float lon) {
+  double sl, cl, so, co;
+  sincos(static_cast<double>(lat), &sl, &cl);
+  sincos(static_cast<double>(lon), &so, &co);
+  return make_float3(static_cast<float>(cl * co), static_cast<float>(cl * so), static_cast<float>(sl));
+}
+
+// Upper bound of |fp32 chord^2 - true chord^2| for two float32 unit vectors built by ag_unit_vec
+// (coordinate error <= 2^-24 each, one rounding per subtraction / multiply / add).
+__device__ __forceinline__ float ag_chord2_err(float c2) { return 6.0e-7f * sqrtf(c2) + 4.0e-7f * c2 + 2.0e-13f; }
+
+// Enumerate the runs of binned points that can hold a point within angular distance R of any
+// target in the box lat in [lat_lo, lat_hi], wrapped longitude in [lon_lo, lon_hi] (lon_lo <=
+// lon_hi, both in [0, 2pi]).  f(first, last) receives half-open ranges into the binned array.
+// Every value is identical across the wave when the arguments are.
+template <class F>
+__device__ __forceinline__ void ag_for_each_range(const AgGrid& g, const int* __restrict__ cell_start, double lat_lo,
+                                                  double lat_hi, double lon_lo, double lon_hi, double R, F&& f) {
+  const double pad = 1.0e-7 + 1.0e-6 * R;
+  const double top = lat_hi + R + pad, bot = lat_lo - R - pad;
+  const int b0 = ag_band_of(g, top), b1 = ag_band_of(g, bot);
+  const double phit = fmax(fabs(lat_lo), fabs(lat_hi));
+  bool full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
+  double lo = 0.0, hi = 0.0;
+  if (!full) {
+    const double q = sin(R) / cos(phit);
+    if (q >= 1.0) {
+      full = true;
+    } else {
+      const double delta = asin(q) * (1.0 + 1.0e-6) + pad;
+      lo = lon_lo - delta;
+      hi = lon_hi + delta;
+      if (hi - lo >= AG_TWO_PI) full = true;
+    }
+  }
+  for (int b = b0; b <= b1; ++b) {
+    const int nc = g.ncols[b];
+    const int base = g.off[b];
+    if (full || nc == 1) {
+      f(cell_start[base], cell_start[base + nc]);
+      continue;
+    }
+    const double w = nc * AG_INV_TWO_PI;
+    const long long ca = static_cast<long long>(floor(lo * w));
+    const long long cb = static_cast<long long>(floor(hi * w));
+    const long long len = cb - ca + 1;
+    if (len >= nc) {
+      f(cell_start[base], cell_start[base + nc]);
+      continue;
+    }
+    int cam = static_cast<int>(ca % nc);
+    if (cam < 0) cam += nc;
+    if (cam + len <= nc) {
+      f(cell_start[base + cam], cell_start[base + cam + static_cast<int>(len)]);
+    } else {
+      f(cell_start[base + cam], cell_start[base + nc]);
+      f(cell_start[base], cell_start[base + cam + static_cast<int>(len) - nc]);
+    }
+  }
+}
+
+__device__ __forceinline__ int ag_lane() { return threadIdx.x & 63; }
+
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------------------------------------
+// host-side declarations shared between translation units
+// ---------------------------------------------------------------------------------------------
+struct AgBinned {
+  AgGrid grid;
+  int64_t n = 0;
+  int64_t ncells_ub = 0;        // host-side upper bound of the number of cells
+  const float4* pts = nullptr;  // [n]  (x, y, z, bits of original id) in binned order
+  const uint64_t* keys = nullptr;  // [n] (cell << 32 | original id), sorted
+  const int* cell_start = nullptr; // [ncells_ub + 1]
+};
+
+// Number of latitude bands for cells of about `delta` radians.
+int ag_grid_bands(double delta);
+// Bins n points into a grid of nb bands; carves everything it needs from `ws`, with the cell
+// tables sized for nb_reserve (>= nb) bands so that the carve can be made independent of nb.
+// out == nullptr: sizing pass only.
+int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, bool want_pts,
+                  hipStream_t stream, AgBinned* out);
+
+// device-wide primitives (rocPRIM behind a plain interface)
+size_t ag_sort_u64_temp_bytes(int64_t n);
+int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t* d_out, int64_t n, int begin_bit,
+                int end_bit, hipStream_t stream);
+size_t ag_scan_i64_temp_bytes(int64_t n);
+// exclusive prefix sum of n int64 counts into d_out[0..n] (n+1 entries; d_out[n] = total); in-place allowed
+int ag_exclusive_scan_i64(void* d_temp, size_t temp_bytes, const int64_t* d_in, int64_t* d_out, int64_t n,
+                          hipStream_t stream);

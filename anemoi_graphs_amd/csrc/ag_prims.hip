@@ -1,0 +1,235 @@
+// Device-wide sort / scan / select primitives (rocPRIM) behind plain functions, error slot,
+// and the small id-manipulation kernels of the masking path.
+#include <stdarg.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ag_common.hpp"
+
+std::string& ag_error_slot() {
+  static thread_local std::string slot;
+  return slot;
+}
+
+int ag_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  ag_error_slot() = buf;
+  return code;
+}
+
+extern "C" const char* ag_last_error(void) { return ag_error_slot().c_str(); }
+extern "C" int ag_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------------------
+size_t ag_sort_u64_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  uint64_t* p = nullptr;
+  (void)rocprim::radix_sort_keys(nullptr, bytes, p, p, static_cast<size_t>(n > 0 ? n : 1), 0u, 64u, hipStream_t(0));
+  return bytes + 256;
+}
+
+int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t* d_out, int64_t n, int begin_bit,
+                int end_bit, hipStream_t stream) {
+  if (n <= 0) return AG_OK;
+  // rocPRIM's merge-sort path builds its bit mask as (1 << end_bit) - 1: end_bit == 64 is only
+  // safe together with begin_bit == 0 (no mask)
+  if (end_bit >= 64 && begin_bit > 0) return ag_fail(AG_ERR_INVALID, "ag_sort_u64: partial sort must end below bit 64");
+  if (end_bit <= begin_bit) {
+    AG_HIP(hipMemcpyAsync(d_out, d_in, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+    return AG_OK;
+  }
+  AG_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_in, d_out, static_cast<size_t>(n),
+                                  static_cast<unsigned>(begin_bit), static_cast<unsigned>(end_bit), stream));
+  return AG_OK;
+}
+
+size_t ag_scan_i64_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  int64_t* p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, bytes, p, p, int64_t(0), static_cast<size_t>(n + 1), rocprim::plus<int64_t>(),
+                                hipStream_t(0));
+  return bytes + 256;
+}
+
+__global__ void ag_zero_i64_kernel(int64_t* p) { *p = 0; }
+
+int ag_exclusive_scan_i64(void* d_temp, size_t temp_bytes, const int64_t* d_in, int64_t* d_out, int64_t n,
+                          hipStream_t stream) {
+  // scan n+1 entries with a zero appended so that d_out[n] holds the total
+  int64_t* in = const_cast<int64_t*>(d_in);
+  hipLaunchKernelGGL(ag_zero_i64_kernel, dim3(1), dim3(1), 0, stream, in + n);
+  AG_LAUNCH_CHECK();
+  AG_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_out, int64_t(0), static_cast<size_t>(n + 1),
+                                 rocprim::plus<int64_t>(), stream));
+  return AG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// masking path
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t ag_mask_compact_workspace_bytes(int64_t n) {
+  size_t bytes = 0;
+  rocprim::counting_iterator<int32_t> ids(0);
+  (void)rocprim::select(nullptr, bytes, ids, static_cast<const uint8_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                        static_cast<int64_t*>(nullptr), static_cast<size_t>(n > 0 ? n : 1), hipStream_t(0));
+  return bytes + 512;
+}
+
+extern "C" int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids, int64_t* d_count, void* d_ws,
+                               size_t ws_bytes, void* stream) {
+  AG_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "ag_mask_compact: n out of range");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    hipLaunchKernelGGL(ag_zero_i64_kernel, dim3(1), dim3(1), 0, s, d_count);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+  }
+  if (ws_bytes < ag_mask_compact_workspace_bytes(n)) return ag_fail(AG_ERR_WORKSPACE, "ag_mask_compact: workspace too small");
+  rocprim::counting_iterator<int32_t> ids(0);
+  size_t bytes = ws_bytes;
+  AG_HIP(rocprim::select(d_ws, bytes, ids, d_mask, d_ids, d_count, static_cast<size_t>(n), s));
+  return AG_OK;
+}
+
+__global__ void ag_gather_coords_kernel(const float2* __restrict__ x, const int32_t* __restrict__ ids, int64_t n,
+                                        float2* __restrict__ out) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    out[i] = x[ids[i]];
+}
+
+extern "C" int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream) {
+  if (n <= 0) return AG_OK;
+  hipLaunchKernelGGL(ag_gather_coords_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_x), d_ids, n,
+                     reinterpret_cast<float2*>(d_out));
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+__global__ void ag_remap_ids_kernel(int32_t* __restrict__ v, int64_t n, const int32_t* __restrict__ map) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    v[i] = map[v[i]];
+}
+
+extern "C" int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream) {
+  if (n <= 0) return AG_OK;
+  hipLaunchKernelGGL(ag_remap_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_values, n, d_map);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge list sort / unique
+// ---------------------------------------------------------------------------------------------
+__global__ void ag_pack_edges_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ tgt, int64_t E,
+                                     int by_target, uint64_t* __restrict__ keys) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < E; i += int64_t(gridDim.x) * blockDim.x) {
+    // ids may be negative (the reference's own concat_edges test uses negative ids): flip the sign
+    // bit so that the unsigned key order equals the signed order
+    const uint64_t s = static_cast<uint32_t>(src[i]) ^ 0x80000000u, t = static_cast<uint32_t>(tgt[i]) ^ 0x80000000u;
+    keys[i] = by_target ? ((t << 32) | s) : ((s << 32) | t);
+  }
+}
+
+__global__ void ag_unpack_edges_kernel(const uint64_t* __restrict__ keys, int64_t E, int by_target,
+                                       int32_t* __restrict__ src, int32_t* __restrict__ tgt) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < E; i += int64_t(gridDim.x) * blockDim.x) {
+    const uint64_t k = keys[i];
+    const int32_t hi = static_cast<int32_t>(static_cast<uint32_t>(k >> 32) ^ 0x80000000u);
+    const int32_t lo = static_cast<int32_t>(static_cast<uint32_t>(k) ^ 0x80000000u);
+    src[i] = by_target ? lo : hi;
+    tgt[i] = by_target ? hi : lo;
+  }
+}
+
+__global__ void ag_unpack_unique_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ count,
+                                        int32_t* __restrict__ src, int32_t* __restrict__ tgt) {
+  const int64_t E = *count;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < E; i += int64_t(gridDim.x) * blockDim.x) {
+    const uint64_t k = keys[i];
+    src[i] = static_cast<int32_t>(static_cast<uint32_t>(k >> 32) ^ 0x80000000u);
+    tgt[i] = static_cast<int32_t>(static_cast<uint32_t>(k) ^ 0x80000000u);
+  }
+}
+
+static size_t ag_unique_temp_bytes(int64_t E) {
+  size_t bytes = 0;
+  uint64_t* p = nullptr;
+  (void)rocprim::unique(nullptr, bytes, p, p, static_cast<int64_t*>(nullptr), static_cast<size_t>(E > 0 ? E : 1),
+                        rocprim::equal_to<uint64_t>(), hipStream_t(0));
+  return bytes + 256;
+}
+
+struct AgSortWs {
+  uint64_t *a, *b;
+  void* temp;
+  size_t temp_bytes;
+};
+
+static size_t ag_sort_ws_carve(AgCarver& c, int64_t E, AgSortWs* w) {
+  const int64_t n = E > 0 ? E : 1;
+  size_t t1 = ag_sort_u64_temp_bytes(n), t2 = ag_unique_temp_bytes(n);
+  size_t tb = t1 > t2 ? t1 : t2;
+  uint64_t* a = c.take<uint64_t>(n);
+  uint64_t* b = c.take<uint64_t>(n);
+  void* temp = c.take<char>(tb);
+  if (w) *w = {a, b, temp, tb};
+  return c.total();
+}
+
+extern "C" size_t ag_sort_edges_workspace_bytes(int64_t E) {
+  AgCarver c(nullptr);
+  return ag_sort_ws_carve(c, E, nullptr);
+}
+
+extern "C" int ag_sort_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int by_target, void* d_ws, size_t ws_bytes,
+                             void* stream) {
+  AG_REQUIRE(E >= 0, "ag_sort_edges: negative edge count");
+  if (E == 0) return AG_OK;
+  if (ws_bytes < ag_sort_edges_workspace_bytes(E)) return ag_fail(AG_ERR_WORKSPACE, "ag_sort_edges: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AgCarver c(d_ws);
+  AgSortWs w;
+  ag_sort_ws_carve(c, E, &w);
+  const int nb = ag_blocks(E, 256, 8192);
+  hipLaunchKernelGGL(ag_pack_edges_kernel, dim3(nb), dim3(256), 0, s, d_src, d_tgt, E, by_target, w.a);
+  AG_LAUNCH_CHECK();
+  int rc = ag_sort_u64(w.temp, w.temp_bytes, w.a, w.b, E, 0, 64, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ag_unpack_edges_kernel, dim3(nb), dim3(256), 0, s, w.b, E, by_target, d_src, d_tgt);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+extern "C" int ag_unique_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int64_t* d_num_unique, void* d_ws,
+                               size_t ws_bytes, void* stream) {
+  AG_REQUIRE(E >= 0, "ag_unique_edges: negative edge count");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (E == 0) {
+    hipLaunchKernelGGL(ag_zero_i64_kernel, dim3(1), dim3(1), 0, s, d_num_unique);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+  }
+  if (ws_bytes < ag_sort_edges_workspace_bytes(E)) return ag_fail(AG_ERR_WORKSPACE, "ag_unique_edges: workspace too small");
+  AgCarver c(d_ws);
+  AgSortWs w;
+  ag_sort_ws_carve(c, E, &w);
+  const int nb = ag_blocks(E, 256, 8192);
+  hipLaunchKernelGGL(ag_pack_edges_kernel, dim3(nb), dim3(256), 0, s, d_src, d_tgt, E, 0, w.a);
+  AG_LAUNCH_CHECK();
+  int rc = ag_sort_u64(w.temp, w.temp_bytes, w.a, w.b, E, 0, 64, s);
+  if (rc) return rc;
+  size_t tb = w.temp_bytes;
+  AG_HIP(rocprim::unique(w.temp, tb, w.b, w.a, d_num_unique, static_cast<size_t>(E), rocprim::equal_to<uint64_t>(), s));
+  hipLaunchKernelGGL(ag_unpack_unique_kernel, dim3(nb), dim3(256), 0, s, w.a, d_num_unique, d_src, d_tgt);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}

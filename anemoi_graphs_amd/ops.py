@@ -1,0 +1,271 @@
+"""Tensor-level entry to the HIP kernels: every function here launches on the current HIP stream
+of the tensors' device and returns device tensors.  PyTorch only provides memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+NORMS = {None: 0, "l1": 1, "l2": 2, "unit-max": 3, "unit-range": 4, "unit-std": 5}
+
+
+def device_of(*tensors: torch.Tensor) -> torch.device:
+    """The HIP device the work runs on: that of the first device tensor, else the current one."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "anemoi_graphs_amd needs an AMD GPU (MI355X / gfx950): no HIP device is visible and "
+            "there is no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def coords(x, device: torch.device) -> torch.Tensor:
+    """float32 contiguous [N,2] copy/view of node coordinates on ``device``."""
+    t = torch.as_tensor(x)
+    if t.ndim != 2 or t.shape[1] != 2:
+        raise ValueError(f"coordinates must have shape [N, 2], got {tuple(t.shape)}")
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t: torch.Tensor | None):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False, return_stats: bool = False):
+    """ids [Nt,k] int32 of the k nearest sources of every target, ascending distance."""
+    lib = _lib.load()
+    dev = device_of(src, tgt)
+    src, tgt = coords(src, dev), coords(tgt, dev)
+    ns, nt = src.shape[0], tgt.shape[0]
+    if k > ns:
+        # what scikit-learn raises in the reference (sklearn/neighbors/_base.py, kneighbors)
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ns}")
+    with torch.cuda.device(dev):
+        out = torch.empty((nt, k), dtype=torch.int32, device=dev)
+        dist = torch.empty((nt, k), dtype=torch.float64, device=dev) if return_dist else None
+        stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
+        _lib.check(
+            lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(out), _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(),
+                       _stream(dev)),
+            "ag_knn",
+        )
+    res = (out,)
+    if return_dist:
+        res += (dist,)
+    if return_stats:
+        res += (stats,)
+    return res[0] if len(res) == 1 else res
+
+
+def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
+    """0-dim float64 device tensor: max over the nodes of the distance to the nearest other node."""
+    lib = _lib.load()
+    dev = device_of(x)
+    x = coords(x, dev)
+    n = x.shape[0]
+    if n < 2:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = 2, n_samples_fit = {n}")
+    with torch.cuda.device(dev):
+        out = torch.zeros((), dtype=torch.float64, device=dev)
+        ws = _workspace(lib.ag_nn_maxdist_workspace_bytes(n), dev)
+        _lib.check(lib.ag_nn_maxdist(_ptr(x), n, _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "ag_nn_maxdist")
+    return out
+
+
+def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, sort: bool = True) -> torch.Tensor:
+    """edge_index [2,E] int32 (row 0 source id, row 1 target id), target-major."""
+    lib = _lib.load()
+    dev = device_of(src, tgt)
+    src, tgt = coords(src, dev), coords(tgt, dev)
+    ns, nt = src.shape[0], tgt.shape[0]
+    radius = float(radius)
+    with torch.cuda.device(dev):
+        offsets = torch.empty(nt + 1, dtype=torch.int64, device=dev)
+        ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
+        _lib.check(
+            lib.ag_radius_count(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), _ptr(ws), ws.numel(), _stream(dev)),
+            "ag_radius_count",
+        )
+        num_edges = int(offsets[nt].item())  # the one host synchronisation: the output size
+        edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
+        if num_edges:
+            _lib.check(
+                lib.ag_radius_fill(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), _ptr(edge_index[0]),
+                                   _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_radius_fill",
+            )
+            if sort:
+                sort_edges_(edge_index, by_target=True)
+    return edge_index
+
+
+def sort_edges_(edge_index: torch.Tensor, by_target: bool = True) -> torch.Tensor:
+    """Canonical in-place sort of a [2,E] int32 device edge list."""
+    lib = _lib.load()
+    dev = edge_index.device
+    assert edge_index.dtype == torch.int32 and edge_index.is_contiguous() and edge_index.shape[0] == 2
+    num_edges = edge_index.shape[1]
+    with torch.cuda.device(dev):
+        ws = _workspace(lib.ag_sort_edges_workspace_bytes(num_edges), dev)
+        _lib.check(
+            lib.ag_sort_edges(_ptr(edge_index[0]), _ptr(edge_index[1]), num_edges, int(by_target), _ptr(ws), ws.numel(),
+                              _stream(dev)),
+            "ag_sort_edges",
+        )
+    return edge_index
+
+
+def unique_edges(edge_index: torch.Tensor) -> torch.Tensor:
+    """Columns sorted by (source, target) with duplicates removed (``torch.unique(dim=1)`` order)."""
+    lib = _lib.load()
+    dev = device_of(edge_index)
+    e = edge_index.to(device=dev, dtype=torch.int32).contiguous().clone()
+    num_edges = e.shape[1]
+    with torch.cuda.device(dev):
+        count = torch.zeros((), dtype=torch.int64, device=dev)
+        ws = _workspace(lib.ag_sort_edges_workspace_bytes(num_edges), dev)
+        _lib.check(
+            lib.ag_unique_edges(_ptr(e[0]), _ptr(e[1]), num_edges, _ptr(count), _ptr(ws), ws.numel(), _stream(dev)),
+            "ag_unique_edges",
+        )
+        n = int(count.item())
+    return e[:, :n].contiguous()
+
+
+def mask_ids(mask: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """int32 ids of the true entries of a boolean node mask."""
+    lib = _lib.load()
+    m = torch.as_tensor(mask).reshape(-1).to(device=device, dtype=torch.uint8).contiguous()
+    n = m.numel()
+    with torch.cuda.device(device):
+        ids = torch.empty(n, dtype=torch.int32, device=device)
+        count = torch.zeros((), dtype=torch.int64, device=device)
+        ws = _workspace(lib.ag_mask_compact_workspace_bytes(n), device)
+        _lib.check(lib.ag_mask_compact(_ptr(m), n, _ptr(ids), _ptr(count), _ptr(ws), ws.numel(), _stream(device)),
+                   "ag_mask_compact")
+        c = int(count.item())
+    return ids[:c]
+
+
+def gather_coords(x: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    dev = x.device
+    out = torch.empty((ids.numel(), 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.ag_gather_coords(_ptr(x), _ptr(ids), ids.numel(), _ptr(out), _stream(dev)), "ag_gather_coords")
+    return out
+
+
+def remap_ids_(values: torch.Tensor, id_map: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    dev = values.device
+    assert values.dtype == torch.int32 and values.is_contiguous() and id_map.dtype == torch.int32
+    with torch.cuda.device(dev):
+        _lib.check(lib.ag_remap_ids(_ptr(values), values.numel(), _ptr(id_map), _stream(dev)), "ag_remap_ids")
+    return values
+
+
+def icosphere(resolution: int, device: torch.device | None = None):
+    """(xyz float64 [V,3], faces int32 [F,3], latlon float32 [V,2] in node order, order int32 [V], rank int32 [V])."""
+    lib = _lib.load()
+    dev = device_of() if device is None else device
+    v, f = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.ag_icosphere_sizes(resolution, ctypes.byref(v), ctypes.byref(f)), "ag_icosphere_sizes")
+    nv, nf = v.value, f.value
+    with torch.cuda.device(dev):
+        xyz = torch.empty((nv, 3), dtype=torch.float64, device=dev)
+        faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
+        latlon = torch.empty((nv, 2), dtype=torch.float32, device=dev)
+        order = torch.empty(nv, dtype=torch.int32, device=dev)
+        rank = torch.empty(nv, dtype=torch.int32, device=dev)
+        ws = _workspace(lib.ag_icosphere_workspace_bytes(resolution), dev)
+        _lib.check(
+            lib.ag_icosphere(resolution, _ptr(xyz), _ptr(faces), _ptr(latlon), _ptr(order), _ptr(rank), _ptr(ws),
+                             ws.numel(), _stream(dev)),
+            "ag_icosphere",
+        )
+    return xyz, faces, latlon, order, rank
+
+
+def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: torch.Tensor,
+                     active: torch.Tensor | None = None) -> torch.Tensor:
+    """edge_index [2,E] int32 of the multi-scale icosahedral edges, sorted by (target, source)."""
+    lib = _lib.load()
+    dev = rank.device
+    lv = (ctypes.c_int32 * len(levels))(*[int(v) for v in levels])
+    act = None if active is None else active.to(device=dev, dtype=torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        count = torch.zeros((), dtype=torch.int64, device=dev)
+        ws = _workspace(lib.ag_multiscale_workspace_bytes(max_resolution, len(levels), x_hops), dev)
+        _lib.check(
+            lib.ag_multiscale_count(max_resolution, lv, len(levels), x_hops, _ptr(rank), _ptr(act), _ptr(count),
+                                    _ptr(ws), ws.numel(), _stream(dev)),
+            "ag_multiscale_count",
+        )
+        num_edges = int(count.item())
+        edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
+        if num_edges:
+            _lib.check(
+                lib.ag_multiscale_fill(max_resolution, lv, len(levels), x_hops, _ptr(rank), _ptr(act), num_edges,
+                                       _ptr(edge_index[0]), _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_multiscale_fill",
+            )
+    return edge_index
+
+
+def edge_attrs(src_x: torch.Tensor, tgt_x: torch.Tensor, edge_index: torch.Tensor, want_len: bool = True,
+               want_dir: bool = True, rotated: bool = True):
+    """Raw EdgeLength [E] and EdgeDirection [E,2] float32 values of an edge list."""
+    lib = _lib.load()
+    dev = device_of(edge_index, src_x, tgt_x)
+    src_x, tgt_x = coords(src_x, dev), coords(tgt_x, dev)
+    e = edge_index.to(device=dev, dtype=torch.int32).contiguous()
+    num_edges = e.shape[1]
+    with torch.cuda.device(dev):
+        length = torch.empty(num_edges, dtype=torch.float32, device=dev) if want_len else None
+        direction = torch.empty((num_edges, 2), dtype=torch.float32, device=dev) if want_dir else None
+        _lib.check(
+            lib.ag_edge_attrs(_ptr(src_x), src_x.shape[0], _ptr(tgt_x), tgt_x.shape[0], _ptr(e[0]), _ptr(e[1]),
+                              num_edges, 1 if rotated else 0, _ptr(length), _ptr(direction), _stream(dev)),
+            "ag_edge_attrs",
+        )
+    return length, direction
+
+
+def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False) -> torch.Tensor:
+    """In-place global normalisation of a float32 device tensor (all elements reduced together)."""
+    if norm not in NORMS:
+        raise ValueError(
+            f"Attribute normalisation \"{norm}\" is not valid. Options are: 'l1', 'l2', 'unit-max' or 'unit-std'."
+        )
+    if NORMS[norm] == 0 and not invert:
+        return values
+    lib = _lib.load()
+    dev = values.device
+    assert values.dtype == torch.float32 and values.is_contiguous()
+    n = values.numel()
+    with torch.cuda.device(dev):
+        ws = _workspace(lib.ag_normalise_workspace_bytes(n), dev)
+        _lib.check(lib.ag_normalise(_ptr(values), n, NORMS[norm], int(invert), _ptr(ws), ws.numel(), _stream(dev)),
+                   "ag_normalise")
+    return values
+
+
+def rdist_to_dist(r: float) -> float:
+    return 2.0 * math.asin(math.sqrt(r))

@@ -1,0 +1,167 @@
+/*
+ * C ABI of libanemoi_graphs_hip.so -- the MI355X (gfx950) graph-construction hot path.
+ *
+ * The reference (ecmwf/anemoi-graphs) has no FFI on this path: its builders are Python
+ * classes that call scikit-learn / trimesh / networkx / scipy on the CPU.  Each entry point
+ * below replaces one of those third-party calls; the comment above it cites the reference
+ * call site it stands in for (paths relative to /root/reference/src/anemoi/graphs).
+ *
+ * Conventions
+ *  - every pointer named d_* is DEVICE memory owned by the caller; nothing is allocated or
+ *    freed inside the library.  Scratch memory comes from a caller-provided workspace whose
+ *    minimum size the matching *_workspace_bytes() function returns.
+ *  - coordinates are float32 [N,2] row-major (latitude, longitude) in radians, the layout of
+ *    `graph[name].x` (nodes/builders/base.py:25,99-101).
+ *  - node ids are int32 (edges/builder.py:87), sizes and offsets int64.
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); the functions do not
+ *    synchronise unless stated.
+ *  - return value 0 = success, negative = error; ag_last_error() gives the message of the
+ *    last failure on the calling thread.
+ */
+#ifndef ANEMOI_GRAPHS_HIP_H
+#define ANEMOI_GRAPHS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG_OK 0
+#define AG_ERR_INVALID (-1)
+#define AG_ERR_WORKSPACE (-2)
+#define AG_ERR_HIP (-3)
+
+const char* ag_last_error(void);
+int ag_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * k nearest neighbours on the sphere.
+ * Replaces NearestNeighbors(metric="haversine").fit(src).kneighbors_graph(tgt, k, "distance")
+ * (edges/builder.py:259-265).  For every target t, d_out_src[t*k + j] is the id of its j-th
+ * nearest source, ascending in the float64 haversine "rdist"
+ * sin^2(dlat/2) + cos(lat_t) cos(lat_s) sin^2(dlon/2) of the float32 inputs; exact float64
+ * ties are broken towards the lower source id.  d_out_dist (nullable) receives the distance
+ * 2*asin(sqrt(rdist)) in radians.  d_stats (nullable, int64[4]) receives: [0] targets resolved
+ * by the float64 wave-per-target path, [1] passes of that path beyond the first window.
+ * Requires 1 <= k <= ns and k <= AG_KNN_MAX_K.
+ */
+#define AG_KNN_MAX_K 64
+size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k);
+int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, int32_t* d_out_src,
+           double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Grid reference distance.
+ * Replaces utils.get_grid_reference_distance (utils.py:61-63): kneighbors(pts, 2) on the set
+ * itself and dists[dists > 0].max().  Writes the float64 result (radians) to *d_out_max
+ * (0.0 if no positive distance exists).
+ */
+size_t ag_nn_maxdist_workspace_bytes(int64_t n);
+int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Radius (cut-off) query.
+ * Replaces NearestNeighbors(metric="haversine").fit(src).radius_neighbors_graph(tgt, radius)
+ * (edges/builder.py:364-366): all (source, target) pairs with rdist <= sin^2(radius/2).
+ * Two calls sharing one workspace: ag_radius_count bins the sources and writes the
+ * exclusive prefix sum of the per-target match counts to d_offsets[0..nt] (d_offsets[nt] =
+ * number of edges E); the caller reads E, allocates, and calls ag_radius_fill with the SAME
+ * arguments and the SAME untouched workspace.  Rows are target-major; inside a row source
+ * ids ascend.  d_out_tgt may be NULL.
+ */
+size_t ag_radius_workspace_bytes(int64_t ns, int64_t nt);
+int ag_radius_count(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
+                    int64_t* d_offsets, void* d_ws, size_t ws_bytes, void* stream);
+int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
+                   const int64_t* d_offsets, int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws,
+                   size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Icosphere nodes.
+ * Replaces trimesh.creation.icosphere(subdivisions=R, radius=1.0) + cartesian_to_latlon_rad +
+ * get_coordinates_ordering (generate/tri_icosahedron.py:47-49,121-122; generate/transforms.py:
+ * 50-52; generate/utils.py:30-32).  Sizes: V = 10*4^R + 2, F = 20*4^R.
+ *   d_xyz      float64 [V,3]  unit vertices in trimesh vertex order (level-l vertices are a prefix)
+ *   d_faces    int32   [F,3]  faces of level R
+ *   d_latlon   float32 [V,2]  (lat, lon) of the vertices in NODE order: latitude descending,
+ *                             ties longitude descending, remaining ties vertex id descending
+ *                             (what generate/utils.py:30-32 yields with stable sorts)
+ *   d_order    int32   [V]    node -> vertex  (the reference's `node_ordering`)
+ *   d_rank     int32   [V]    vertex -> node  (inverse permutation)
+ */
+#define AG_ICO_MAX_LEVEL 11
+int ag_icosphere_sizes(int R, int64_t* V, int64_t* F);
+size_t ag_icosphere_workspace_bytes(int R);
+int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_t* d_order, int32_t* d_rank,
+                 void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-scale icosahedral edges.
+ * Replaces tri_icosahedron.add_edges_to_nx_graph (generate/tri_icosahedron.py:165-188) and
+ * nx.to_scipy_sparse_array (edges/builder.py:453): for every level in `levels` all ordered
+ * pairs of distinct level-l vertices within x_hops mesh hops, in node numbering (d_rank of
+ * ag_icosphere for R = max level), de-duplicated over levels.  Output is sorted by
+ * (target, source).  Two calls: count -> *d_num_edges (int64, device), then fill.
+ * d_active (nullable, uint8 [V]) restricts every level's mesh to edges whose two vertices are
+ * active (generate/tri_icosahedron.py:214-215).
+ */
+#define AG_MULTISCALE_MAX_HOPS 8
+size_t ag_multiscale_workspace_bytes(int R, int nlevels, int x_hops);
+int ag_multiscale_count(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
+                        const uint8_t* d_active, int64_t* d_num_edges, void* d_ws, size_t ws_bytes, void* stream);
+int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
+                       const uint8_t* d_active, int64_t num_edges, int32_t* d_out_src, int32_t* d_out_tgt,
+                       void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Edge attributes.
+ * Replaces EdgeLength.get_raw_values -> utils.haversine_distance (edges/attributes.py:144-148,
+ * utils.py:99-103; float32 arithmetic) and EdgeDirection.get_raw_values ->
+ * directional_edge_features (edges/attributes.py:100-104, edges/directional.py:40-94; float32
+ * unit vectors, float64 rotation).  Either output may be NULL.  flags: bit0 = rotated
+ * direction features (luse_rotated_features).
+ *   d_len  float32 [E]     great-circle angle in radians
+ *   d_dir  float32 [E,2]
+ */
+#define AG_ATTR_ROTATED 1
+int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt, const int32_t* d_edge_src,
+                  const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len, float* d_dir, void* stream);
+
+/* Global normalisation of an attribute array in place.
+ * Replaces NormaliserMixin.normalise (normalise.py:36-55) + the float32 cast and the
+ * optional `1 - v` of EdgeLength.post_process (edges/attributes.py:33-40,150-157).
+ * norm: 0 none, 1 l1, 2 l2, 3 unit-max, 4 unit-range, 5 unit-std.  n = number of float32
+ * elements (E*M).  The reductions run over ALL elements, in float64. */
+size_t ag_normalise_workspace_bytes(int64_t n);
+int ag_normalise(float* d_values, int64_t n, int norm, int invert, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Edge list utilities.
+ * ag_sort_edges: canonical sort of E (source, target) pairs in place, by (target, source) when
+ * by_target != 0 else by (source, target).
+ * ag_unique_edges: sort by (source, target) and drop duplicates; replaces utils.concat_edges'
+ * torch.unique(dim=1) (utils.py:81) on the concatenated list.  *d_num_unique (int64, device).
+ */
+size_t ag_sort_edges_workspace_bytes(int64_t E);
+int ag_sort_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int by_target, void* d_ws, size_t ws_bytes,
+                  void* stream);
+int ag_unique_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int64_t* d_num_unique, void* d_ws,
+                    size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Node masking (edges/builder.py:162-193).
+ * ag_mask_compact: ids of the true entries of a uint8 mask, ascending -> d_ids, count ->
+ * *d_count (int64, device); ag_gather_coords: out[i] = x[ids[i]]; ag_remap_ids: v[i] = map[v[i]].
+ */
+size_t ag_mask_compact_workspace_bytes(int64_t n);
+int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids, int64_t* d_count, void* d_ws,
+                    size_t ws_bytes, void* stream);
+int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream);
+int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -44,11 +44,14 @@ def _attrs(ref, g, name, out, prefix):
     out[f"{prefix}dir_plain_none"] = ref.EdgeDirection(norm=None, luse_rotated_features=False).compute(g, name).numpy()
 
 
-def case_conftest(ref):
-    """The 3x4 grid of /root/reference/tests/conftest.py:16-17,56-63 and the recipe of :99-112."""
+def case_conftest(ref, dtype=np.float64):
+    """The 3x4 grid of /root/reference/tests/conftest.py:16-17,56-63 and the recipe of :99-112.
+    The fixture's coordinates are float64; node builders always produce float32, so a float32 copy
+    of the case is recorded too (the self edges of this self-query have a direction that is pure
+    rounding noise of the coordinate dtype)."""
     lats, lons = [-0.15, 0, 0.15], [0, 0.25, 0.5, 0.75]
     coords = np.array([[lat, lon] for lat in lats for lon in lons])
-    x = (2 * torch.pi * torch.tensor(coords)).numpy()  # float64, as in the fixture
+    x = (2 * torch.pi * torch.tensor(coords)).numpy().astype(dtype)
     g = _graph(ref, test_nodes=x)
     g = ref.KNNEdges("test_nodes", "test_nodes", 3).update_graph(g)
     name = ("test_nodes", "to", "test_nodes")
@@ -179,6 +182,7 @@ def main() -> None:
     OUT.mkdir(parents=True, exist_ok=True)
     cases = {
         "conftest_grid": case_conftest,
+        "conftest_grid_f32": lambda ref: case_conftest(ref, np.float32),
         "random_sphere": case_random,
         "masks": case_masks,
         "regular_2deg": case_regular,

@@ -1,0 +1,89 @@
+"""GPU parity of EdgeLength / EdgeDirection / normalisation (tolerance: 1e-6 relative, as the
+north-star states; absolute floor 1e-6 of the value range for direction components near zero)."""
+import numpy as np
+import pytest
+import torch
+
+from anemoi_graphs_amd import grids, ops
+from oracle import reference_path as rp
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+NORMS = [None, "l1", "l2", "unit-max", "unit-range", "unit-std"]
+
+
+def _tag(norm):
+    return "none" if norm is None else norm.replace("-", "_")
+
+
+def _attrs(src, tgt, e, device, norm=None, rotated=True, invert=False):
+    length, direction = ops.edge_attrs(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device),
+                                       torch.from_numpy(np.ascontiguousarray(e)).to(device), rotated=rotated)
+    length = ops.normalise_(length.reshape(-1, 1), norm, invert)
+    direction = ops.normalise_(direction, norm)
+    return length.cpu().numpy(), direction.cpu().numpy()
+
+
+def _close(got, want, scale=None):
+    scale = np.abs(want).max() if scale is None else scale
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=RTOL * scale)
+
+
+@pytest.mark.parametrize("case,src_key,tgt_key,prefix,ekey", [
+    ("random_sphere", "src", "tgt", "knn3_", "knn3_edge_index"),
+    ("random_sphere", "tgt", "src", "cutoff06_", "cutoff06_edge_index"),
+    ("conftest_grid_f32", "x", "x", "knn3_", "knn3_edge_index"),
+])
+def test_attrs_golden(device, golden, case, src_key, tgt_key, prefix, ekey):
+    g = golden(case)
+    src, tgt, e = g[src_key].astype(np.float32), g[tgt_key].astype(np.float32), g[ekey]
+    for norm in NORMS:
+        length, direction = _attrs(src, tgt, e, device, norm)
+        _close(length, g[f"{prefix}len_{_tag(norm)}"])
+        _close(direction, g[f"{prefix}dir_{_tag(norm)}"])
+    length, _ = _attrs(src, tgt, e, device, "unit-max", invert=True)
+    _close(length, g[f"{prefix}len_inv_unit_max"])
+    _, direction = _attrs(src, tgt, e, device, None, rotated=False)
+    _close(direction, g[f"{prefix}dir_plain_none"])
+
+
+def test_attrs_raw_are_float32_exact_inputs(device, golden):
+    """The float32 unit vectors are bit-identical to numpy's, so short edges (where one float32 ulp
+    of a coordinate is 1e-4 of the edge) still agree to 1e-6."""
+    g = golden("regular_2deg")
+    length, direction = _attrs(g["data"], g["hidden"], g["enc_cutoff06_edge_index"], device)
+    _close(length, g["enc_len_none"])
+    _close(direction, g["enc_dir_none"], scale=1.0)
+
+
+def test_attrs_live_oracle_fine_grid(device):
+    # 0.25-degree neighbours: edge length ~4e-3 rad; poles and the date line included
+    data = grids.regular(0.25)
+    hidden = grids.fibonacci_sphere(40962)
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, len(hidden), 200000)
+    s = rp.knn_edges(data, hidden[np.unique(t)], 4)[0][:200000]
+    t = np.unique(t)[np.arange(len(s)) // 4][: len(s)]
+    e = np.stack([s, t]).astype(np.int32)
+    length, direction = _attrs(data, hidden, e, device)
+    _close(length[:, 0], rp.edge_lengths(data, hidden, e))
+    _close(direction, rp.edge_directions(data, hidden, e), scale=1.0)
+
+
+def test_attrs_degenerate_edges(device):
+    # self edges (length 0), targets exactly at the poles
+    x = np.array([[0.3, 1.0], [np.pi / 2, 0.0], [-np.pi / 2, 2.0], [0.0, 0.0], [1.2, -3.0]], dtype=np.float32)
+    e = np.array([[0, 0, 3, 4, 1, 2, 3], [0, 1, 2, 1, 1, 2, 4]], dtype=np.int32)
+    length, direction = _attrs(x, x, e, device)
+    want_len = rp.edge_lengths(x, x, e)
+    np.testing.assert_allclose(length[:, 0], want_len, rtol=RTOL, atol=1e-9)
+    want_dir = rp.edge_directions(x, x, e)
+    np.testing.assert_allclose(direction, want_dir, rtol=RTOL, atol=1e-6)
+
+
+def test_normalise_errors_and_std_zero(device):
+    v = torch.full((10, 1), 2.5, device=device)
+    assert torch.equal(ops.normalise_(v.clone(), "unit-std"), v)  # std == 0: untouched (normalise.py:49-51)
+    with pytest.raises(ValueError):
+        ops.normalise_(v.clone(), "l3")

@@ -1,0 +1,148 @@
+"""GPU parity of the k-NN / reference-distance / radius kernels against the CPU oracle
+(scikit-learn called exactly as the reference calls it) and the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from anemoi_graphs_amd import grids, ops
+from oracle import reference_path as rp
+from tests import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+
+def _knn_case(src, tgt, k, device):
+    ids, dist, stats = ops.knn(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), k,
+                               return_dist=True, return_stats=True)
+    ids, dist = ids.cpu().numpy(), dist.cpu().numpy()
+    ref, ref_d = rp.knn_edges(src, tgt, k, return_dist=True)
+    ref_rows = h.knn_rows(ref, len(tgt), k)
+    res = h.compare_knn(src, tgt, ids, ref_rows)
+    assert res["bad_rows"] == [], res
+    # distances: ascending, and equal to the reference's (2*asin(sqrt(rdist))) to float64 rounding
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    # (with <= 11 sources scikit-learn switches to its brute-force path, which evaluates the metric on
+    # float32 copies: its distances are only float32-accurate there)
+    rtol = 1e-12 if len(src) > 11 else 1e-6
+    np.testing.assert_allclose(dist, ref_d.reshape(len(tgt), k), rtol=rtol, atol=1e-15)
+    return res, stats.cpu().numpy()
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 20])
+def test_knn_random(device, k):
+    src, tgt = grids.random_sphere(3000, seed=11), grids.random_sphere(20000, seed=12)
+    res, stats = _knn_case(src, tgt, k, device)
+    assert res["tie_rows"] == 0
+    print("knn random", k, res["tie_rows"], stats)
+
+
+def test_knn_regular_grid_with_ties(device):
+    # poles (coincident points), exact symmetric ties
+    src, tgt = grids.fibonacci_sphere(642), grids.regular(2.0)
+    res, stats = _knn_case(src, tgt, 3, device)
+    print("knn regular", res["tie_rows"], stats)
+
+
+def test_knn_regular_to_regular(device):
+    # massive exact ties: every target equidistant from several sources
+    src, tgt = grids.regular(5.0), grids.regular(3.0)
+    res, stats = _knn_case(src, tgt, 4, device)
+    print("knn reg-reg", res["tie_rows"], stats)
+
+
+def test_knn_sparse_targets_dense_sources(device):
+    src, tgt = grids.random_sphere(50000, seed=3), grids.random_sphere(500, seed=4)
+    _knn_case(src, tgt, 5, device)
+
+
+def test_knn_clustered_sources(device):
+    # all sources in a small cap: most targets need the widening float64 path
+    rng = np.random.default_rng(5)
+    src = np.stack([0.3 + 0.05 * rng.standard_normal(2000), 1.0 + 0.05 * rng.standard_normal(2000)], 1).astype(np.float32)
+    tgt = grids.random_sphere(3000, seed=6)
+    res, stats = _knn_case(src, tgt, 3, device)
+    assert stats[0] > 0
+
+
+def test_knn_tiny(device):
+    src = grids.random_sphere(5, seed=1)
+    tgt = grids.random_sphere(7, seed=2)
+    _knn_case(src, tgt, 5, device)
+    with pytest.raises(ValueError):
+        ops.knn(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), 6)
+
+
+def test_knn_golden(device, golden):
+    g = golden("random_sphere")
+    for k in (1, 3, 8):
+        ids = ops.knn(torch.from_numpy(g["src"]).to(device), torch.from_numpy(g["tgt"]).to(device), k).cpu().numpy()
+        ref = h.knn_rows(g[f"knn{k}_edge_index"], len(g["tgt"]), k)
+        assert np.array_equal(ids, ref)  # tie-free input: identical including the in-row order
+    g = golden("o96_tri4")
+    ids = ops.knn(torch.from_numpy(g["hidden"]).to(device), torch.from_numpy(g["data"]).to(device), 3).cpu().numpy()
+    res = h.compare_knn(g["hidden"], g["data"], ids, h.knn_rows(g["dec_knn3_edge_index"], len(g["data"]), 3))
+    assert res["bad_rows"] == [], res
+    print("o96->tri4 tie rows", res["tie_rows"])
+
+
+@pytest.mark.parametrize("name", ["rand5000", "fib642", "reg2.0", "o32"])
+def test_reference_distance(device, name):
+    x = grids.named(name)
+    got = float(ops.nn_maxdist(torch.from_numpy(x).to(device)).item())
+    want = rp.grid_reference_distance(x)
+    assert got == pytest.approx(want, rel=1e-13, abs=0.0), (got, want)
+
+
+def test_reference_distance_golden(device, golden):
+    g = golden("random_sphere")
+    assert float(ops.nn_maxdist(torch.from_numpy(g["src"]).to(device)).item()) == pytest.approx(float(g["refdist_src"]), rel=1e-13)
+    g = golden("regular_2deg")
+    assert float(ops.nn_maxdist(torch.from_numpy(g["data"]).to(device)).item()) == pytest.approx(float(g["refdist_data"]), rel=1e-13)
+
+
+def _radius_case(src, tgt, radius, device):
+    e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius).cpu().numpy()
+    assert np.array_equal(e, h.canonical(e)), "rows must be target-major with ascending source ids"
+    ref = rp.radius_edges(src, tgt, radius)
+    res = h.compare_edge_sets(src, tgt, e, ref, radius)
+    assert res["bad"] == 0, res
+    return res
+
+
+@pytest.mark.parametrize("radius", [0.0, 0.01, 0.05, 0.4, 2.0, 3.1])
+def test_radius_random(device, radius):
+    src, tgt = grids.random_sphere(20000, seed=21), grids.random_sphere(1500, seed=22)
+    if radius > 1.0:
+        src, tgt = src[:2000], tgt[:300]
+    res = _radius_case(src, tgt, radius, device)
+    assert res["boundary"] == 0
+    print("radius", radius, res)
+
+
+def test_radius_whole_sphere(device):
+    # radius >= pi: every pair.  (scikit-learn's threshold sin^2(r/2) is not monotonic beyond pi and
+    # drops near-antipodal pairs there; a cut-off radius beyond pi is meaningless, so the library
+    # saturates instead.)
+    src, tgt = grids.random_sphere(300, seed=1), grids.random_sphere(200, seed=2)
+    e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), 3.2)
+    assert e.shape[1] == 300 * 200
+
+
+def test_radius_regular(device):
+    data, hidden = grids.regular(2.0), grids.fibonacci_sphere(642)
+    radius = rp.cutoff_radius(hidden, 0.6)
+    print(_radius_case(data, hidden, radius, device))
+    # cutoff_factor 1.0: the farthest nearest-neighbour pair sits exactly on the boundary
+    print(_radius_case(hidden, hidden, rp.cutoff_radius(hidden, 1.0), device))
+
+
+def test_radius_golden(device, golden):
+    g = golden("regular_2deg")
+    src, tgt, radius = g["data"], g["hidden"], float(g["enc_cutoff06_radius"])
+    e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius).cpu().numpy()
+    res = h.compare_edge_sets(src, tgt, e, g["enc_cutoff06_edge_index"], radius)
+    assert res["bad"] == 0 and res["boundary"] == 0, res
+    g = golden("o96_tri4")
+    src, tgt, radius = g["data"], g["hidden"], float(g["enc_cutoff06_radius"])
+    e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius).cpu().numpy()
+    assert np.array_equal(e, h.canonical(g["enc_cutoff06_edge_index"]))
