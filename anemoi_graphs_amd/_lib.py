@@ -5,6 +5,9 @@ The library is mandatory: there is no CPU or PyTorch fallback for any operation 
 from __future__ import annotations
 
 import ctypes
+
+import torch  # noqa: F401  -- must come first: the library then binds to the HIP runtime PyTorch loaded
+
 from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
@@ -16,6 +19,8 @@ _P = c_void_p  # every device pointer and the stream travel as void*
 SIGNATURES = {
     "ag_last_error": (c_char_p, []),
     "ag_version": (c_int, []),
+    "ag_profile_enable": (c_int, [c_int]),
+    "ag_profile_collect": (c_int, [ctypes.c_char_p, c_size_t]),
     "ag_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "ag_nn_maxdist_workspace_bytes": (c_size_t, [c_int64]),
@@ -64,10 +69,7 @@ def load() -> ctypes.CDLL:
         )
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError:  # TEMPORARY while the library is being brought up
-            continue
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib

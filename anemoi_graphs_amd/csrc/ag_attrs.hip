@@ -163,10 +163,7 @@ extern "C" int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tg
   AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
   if (E == 0 || (d_len == nullptr && d_dir == nullptr)) return AG_OK;
   AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
-  hipLaunchKernelGGL(ag_edge_attrs_kernel, dim3(ag_blocks(E, 256, 1 << 20)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x),
-                     reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len,
-                     reinterpret_cast<float2*>(d_dir));
+  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, 256, 1 << 20)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir));
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -315,19 +312,18 @@ extern "C" int ag_normalise(float* d_values, int64_t n, int norm, int invert, vo
   AgStats* partial = c.take<AgStats>(AG_RED_BLOCKS);
   const int nblocks = ag_blocks(n, 256 * 8, AG_RED_BLOCKS);
   if (norm != 0) {
-    hipLaunchKernelGGL(ag_reduce_partial_kernel, dim3(nblocks), dim3(256), 0, s, d_values, n, 0, stats, partial);
+    AG_KERNEL("ag_reduce_partial_kernel", ag_reduce_partial_kernel, dim3(nblocks), dim3(256), s, d_values, n, 0, stats, partial);
     AG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ag_reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, 0, stats);
+    AG_KERNEL("ag_reduce_final_kernel", ag_reduce_final_kernel, dim3(1), dim3(256), s, partial, nblocks, 0, stats);
     AG_LAUNCH_CHECK();
     if (norm == 5) {
-      hipLaunchKernelGGL(ag_reduce_partial_kernel, dim3(nblocks), dim3(256), 0, s, d_values, n, 1, stats, partial);
+      AG_KERNEL("ag_reduce_partial_kernel", ag_reduce_partial_kernel, dim3(nblocks), dim3(256), s, d_values, n, 1, stats, partial);
       AG_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ag_reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, 1, stats);
+      AG_KERNEL("ag_reduce_final_kernel", ag_reduce_final_kernel, dim3(1), dim3(256), s, partial, nblocks, 1, stats);
       AG_LAUNCH_CHECK();
     }
   }
-  hipLaunchKernelGGL(ag_normalise_apply_kernel, dim3(ag_blocks(n, 256, 1 << 16)), dim3(256), 0, s, d_values, n, norm,
-                     invert, stats);
+  AG_KERNEL("ag_normalise_apply_kernel", ag_normalise_apply_kernel, dim3(ag_blocks(n, 256, 1 << 16)), dim3(256), s, d_values, n, norm, invert, stats);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

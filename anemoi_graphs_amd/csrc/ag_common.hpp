@@ -34,6 +34,23 @@ int ag_fail(int code, const char* fmt, ...);
 #define AG_LAUNCH_CHECK() AG_HIP(hipGetLastError())
 
 // ---------------------------------------------------------------------------------------------
+// optional per-kernel timing with HIP events recorded on the launch stream (off by default)
+// ---------------------------------------------------------------------------------------------
+void ag_prof_begin(const char* name, hipStream_t stream);
+void ag_prof_end(hipStream_t stream);
+struct AgProfScope {
+  hipStream_t s;
+  AgProfScope(const char* name, hipStream_t stream) : s(stream) { ag_prof_begin(name, s); }
+  ~AgProfScope() { ag_prof_end(s); }
+};
+
+#define AG_KERNEL(name, kernel, grid, block, stream, ...)              \
+  do {                                                                 \
+    AgProfScope ag_prof_scope__(name, stream);                         \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
 // workspace carving: the same code sizes the workspace (base == nullptr) and hands out pointers
 // ---------------------------------------------------------------------------------------------
 struct AgCarver {

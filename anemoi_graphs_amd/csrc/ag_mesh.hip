@@ -204,12 +204,11 @@ static int ag_vertex_bits(int l) {
 // unique edges of `faces` (level l) into w.uniq
 static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, hipStream_t s) {
   const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l);
-  hipLaunchKernelGGL(ag_ico_edge_keys_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), 0, s, faces, F, w.keys_a);
+  AG_KERNEL("ag_ico_edge_keys_kernel", ag_ico_edge_keys_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), s, faces, F, w.keys_a);
   AG_LAUNCH_CHECK();
   int rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, 3 * F, 0, 32 + ag_vertex_bits(l), s);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_ico_unique_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), 0, s, w.keys_b, Eu, w.uniq,
-                     w.error_flag);
+  AG_KERNEL("ag_ico_unique_kernel", ag_ico_unique_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, w.keys_b, Eu, w.uniq, w.error_flag);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -242,20 +241,19 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   // ping-pong between the caller's face buffer and the workspace so that level R lands in d_faces
   int32_t* cur = (R % 2 == 0) ? d_faces : w.faces_a;
   int32_t* nxt = (R % 2 == 0) ? w.faces_a : d_faces;
-  hipLaunchKernelGGL(ag_zero_i32_kernel, dim3(1), dim3(64), 0, s, w.error_flag, int64_t(1));
+  AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(1), dim3(64), s, w.error_flag, int64_t(1));
   AG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ag_ico_init_kernel, dim3(1), dim3(64), 0, s, d_xyz, cur);
+  AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, d_xyz, cur);
   AG_LAUNCH_CHECK();
   for (int l = 0; l < R; ++l) {
     const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
     int rc = ag_topo_unique_edges(w, cur, l, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(ag_ico_midpoints_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), 0, s, w.uniq, Eu, V, d_xyz);
+    AG_KERNEL("ag_ico_midpoints_kernel", ag_ico_midpoints_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, w.uniq, Eu, V, d_xyz);
     AG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), 0, s, cur, F, w.uniq, Eu,
-                       static_cast<int>(V), nxt);
+    AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F, w.uniq, Eu, static_cast<int>(V), nxt);
     AG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ag_ico_project_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), 0, s, d_xyz, V + Eu);
+    AG_KERNEL("ag_ico_project_kernel", ag_ico_project_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), s, d_xyz, V + Eu);
     AG_LAUNCH_CHECK();
     int32_t* t = cur;
     cur = nxt;
@@ -263,20 +261,19 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   }
   const int64_t V = ag_ico_V(R);
   const int vb = ag_blocks(V, 256, 8192);
-  hipLaunchKernelGGL(ag_ico_latlon_kernel, dim3(vb), dim3(256), 0, s, d_xyz, V, latlon);
+  AG_KERNEL("ag_ico_latlon_kernel", ag_ico_latlon_kernel, dim3(vb), dim3(256), s, d_xyz, V, latlon);
   AG_LAUNCH_CHECK();
   // node order: latitude descending, ties longitude descending, ties vertex id descending
   uint64_t* sorted0 = w.uniq;  // E_R >= V_R entries
-  hipLaunchKernelGGL(ag_ico_order_keys0_kernel, dim3(vb), dim3(256), 0, s, latlon, V, w.keys_a);
+  AG_KERNEL("ag_ico_order_keys0_kernel", ag_ico_order_keys0_kernel, dim3(vb), dim3(256), s, latlon, V, w.keys_a);
   AG_LAUNCH_CHECK();
   int rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, sorted0, V, 0, 64, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_ico_order_keys1_kernel, dim3(vb), dim3(256), 0, s, latlon, V, sorted0, w.keys_a);
+  AG_KERNEL("ag_ico_order_keys1_kernel", ag_ico_order_keys1_kernel, dim3(vb), dim3(256), s, latlon, V, sorted0, w.keys_a);
   AG_LAUNCH_CHECK();
   rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, V, 0, 64, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_ico_finish_order_kernel, dim3(vb), dim3(256), 0, s, sorted0, w.keys_b, latlon, V,
-                     reinterpret_cast<float2*>(d_latlon), d_order, d_rank);
+  AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, sorted0, w.keys_b, latlon, V, reinterpret_cast<float2*>(d_latlon), d_order, d_rank);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -429,8 +426,7 @@ static int ag_ms_check(int R, const int32_t* levels, int nlevels, int x_hops) {
 template <int CAP>
 static void ag_ms_launch_pairs(int64_t V, int x_hops, const AgMsWs& m, const int32_t* rank, uint64_t* pairs,
                                hipStream_t s) {
-  hipLaunchKernelGGL(ag_ms_pairs_kernel<CAP>, dim3(ag_blocks(V, 64)), dim3(64), 0, s, V, x_hops, m.deg, m.adj, rank,
-                     pairs);
+  AG_KERNEL("ag_ms_pairs_kernel", ag_ms_pairs_kernel<CAP>, dim3(ag_blocks(V, 64)), dim3(64), s, V, x_hops, m.deg, m.adj, rank, pairs);
 }
 
 extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
@@ -452,9 +448,9 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
 
   int32_t* cur = m.topo.faces_a;
   int32_t* nxt = m.topo.faces_b;
-  hipLaunchKernelGGL(ag_zero_i32_kernel, dim3(1), dim3(64), 0, s, m.topo.error_flag, int64_t(1));
+  AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(1), dim3(64), s, m.topo.error_flag, int64_t(1));
   AG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ag_ico_init_kernel, dim3(1), dim3(64), 0, s, static_cast<double*>(nullptr), cur);
+  AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, static_cast<double*>(nullptr), cur);
   AG_LAUNCH_CHECK();
   int max_level = 0;
   for (int i = 0; i < nlevels; ++i) max_level = levels[i] > max_level ? levels[i] : max_level;
@@ -466,10 +462,9 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
     bool wanted = false;
     for (int i = 0; i < nlevels; ++i) wanted = wanted || (levels[i] == l);
     if (wanted) {
-      hipLaunchKernelGGL(ag_zero_i32_kernel, dim3(ag_blocks(V, 256, 4096)), dim3(256), 0, s, m.deg, V);
+      AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(ag_blocks(V, 256, 4096)), dim3(256), s, m.deg, V);
       AG_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ag_ms_adjacency_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), 0, s, m.topo.uniq, Eu,
-                         d_active, m.deg, m.adj);
+      AG_KERNEL("ag_ms_adjacency_kernel", ag_ms_adjacency_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, m.topo.uniq, Eu, d_active, m.deg, m.adj);
       AG_LAUNCH_CHECK();
       uint64_t* pairs = m.pairs_a + slot_base;
       if (cap <= 6) ag_ms_launch_pairs<6>(V, x_hops, m, d_rank, pairs, s);
@@ -481,8 +476,7 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
       slot_base += V * cap;
     }
     if (l < max_level) {
-      hipLaunchKernelGGL(ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), 0, s, cur, F, m.topo.uniq,
-                         Eu, static_cast<int>(V), nxt);
+      AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F, m.topo.uniq, Eu, static_cast<int>(V), nxt);
       AG_LAUNCH_CHECK();
       int32_t* t = cur;
       cur = nxt;
@@ -492,11 +486,11 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
   const int64_t n = slot_base;
   rc = ag_sort_u64(m.temp, m.temp_bytes, m.pairs_a, m.pairs_b, n, 0, 64, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_ms_flag_unique_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), 0, s, m.pairs_b, n, m.offsets);
+  AG_KERNEL("ag_ms_flag_unique_kernel", ag_ms_flag_unique_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s, m.pairs_b, n, m.offsets);
   AG_LAUNCH_CHECK();
   rc = ag_exclusive_scan_i64(m.temp, m.temp_bytes, m.offsets, m.offsets, n, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_ms_copy_total_kernel, dim3(1), dim3(1), 0, s, m.offsets, n, d_num_edges);
+  AG_KERNEL("ag_ms_copy_total_kernel", ag_ms_copy_total_kernel, dim3(1), dim3(1), s, m.offsets, n, d_num_edges);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -515,8 +509,7 @@ extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int
   AgMsWs m;
   ag_ms_carve(c, R, levels, nlevels, x_hops, &m);
   if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_fill: workspace too small");
-  hipLaunchKernelGGL(ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), 0, s, m.pairs_b, m.offsets,
-                     m.slots, num_edges, d_out_src, d_out_tgt);
+  AG_KERNEL("ag_ms_emit_kernel", ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_b, m.offsets, m.slots, num_edges, d_out_src, d_out_tgt);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

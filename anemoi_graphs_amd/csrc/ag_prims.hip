@@ -24,6 +24,84 @@ int ag_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---------------------------------------------------------------------------------------------
+// event profiler
+// ---------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace {
+struct ProfRec {
+  const char* name;
+  hipEvent_t start, stop;
+};
+std::mutex g_prof_mutex;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+void ag_prof_begin(const char* name, hipStream_t stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  ProfRec r{name, prof_event(), prof_event()};
+  if (r.start) (void)hipEventRecord(r.start, stream);
+  g_prof_recs.push_back(r);
+}
+
+void ag_prof_end(hipStream_t stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  if (!g_prof_recs.empty() && g_prof_recs.back().stop) (void)hipEventRecord(g_prof_recs.back().stop, stream);
+}
+
+extern "C" int ag_profile_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  for (auto& r : g_prof_recs) {
+    if (r.start) g_prof_pool.push_back(r.start);
+    if (r.stop) g_prof_pool.push_back(r.stop);
+  }
+  g_prof_recs.clear();
+  g_prof_on = on != 0;
+  return AG_OK;
+}
+
+extern "C" int ag_profile_collect(char* buf, size_t buf_bytes) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& r : g_prof_recs) {
+    if (!r.start || !r.stop) continue;
+    if (hipEventSynchronize(r.stop) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+    auto& a = agg[r.name];
+    a.first += 1;
+    a.second += ms;
+  }
+  std::string out;
+  for (auto& kv : agg) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (buf && buf_bytes) {
+    snprintf(buf, buf_bytes, "%s", out.c_str());
+  }
+  return static_cast<int>(out.size());
+}
+
 extern "C" const char* ag_last_error(void) { return ag_error_slot().c_str(); }
 extern "C" int ag_version(void) { return 100; }
 
@@ -45,6 +123,7 @@ int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t*
     AG_HIP(hipMemcpyAsync(d_out, d_in, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     return AG_OK;
   }
+  AgProfScope prof("rocprim_radix_sort_keys", stream);
   AG_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_in, d_out, static_cast<size_t>(n),
                                   static_cast<unsigned>(begin_bit), static_cast<unsigned>(end_bit), stream));
   return AG_OK;
@@ -64,7 +143,7 @@ int ag_exclusive_scan_i64(void* d_temp, size_t temp_bytes, const int64_t* d_in, 
                           hipStream_t stream) {
   // scan n+1 entries with a zero appended so that d_out[n] holds the total
   int64_t* in = const_cast<int64_t*>(d_in);
-  hipLaunchKernelGGL(ag_zero_i64_kernel, dim3(1), dim3(1), 0, stream, in + n);
+  AG_KERNEL("ag_zero_i64_kernel", ag_zero_i64_kernel, dim3(1), dim3(1), stream, in + n);
   AG_LAUNCH_CHECK();
   AG_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_out, int64_t(0), static_cast<size_t>(n + 1),
                                  rocprim::plus<int64_t>(), stream));
@@ -87,7 +166,7 @@ extern "C" int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids,
   AG_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "ag_mask_compact: n out of range");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n == 0) {
-    hipLaunchKernelGGL(ag_zero_i64_kernel, dim3(1), dim3(1), 0, s, d_count);
+    AG_KERNEL("ag_zero_i64_kernel", ag_zero_i64_kernel, dim3(1), dim3(1), s, d_count);
     AG_LAUNCH_CHECK();
     return AG_OK;
   }
@@ -106,9 +185,7 @@ __global__ void ag_gather_coords_kernel(const float2* __restrict__ x, const int3
 
 extern "C" int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream) {
   if (n <= 0) return AG_OK;
-  hipLaunchKernelGGL(ag_gather_coords_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_x), d_ids, n,
-                     reinterpret_cast<float2*>(d_out));
+  AG_KERNEL("ag_gather_coords_kernel", ag_gather_coords_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_x), d_ids, n, reinterpret_cast<float2*>(d_out));
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -120,8 +197,7 @@ __global__ void ag_remap_ids_kernel(int32_t* __restrict__ v, int64_t n, const in
 
 extern "C" int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream) {
   if (n <= 0) return AG_OK;
-  hipLaunchKernelGGL(ag_remap_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), d_values, n, d_map);
+  AG_KERNEL("ag_remap_ids_kernel", ag_remap_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), static_cast<hipStream_t>(stream), d_values, n, d_map);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -200,11 +276,11 @@ extern "C" int ag_sort_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int by_t
   AgSortWs w;
   ag_sort_ws_carve(c, E, &w);
   const int nb = ag_blocks(E, 256, 8192);
-  hipLaunchKernelGGL(ag_pack_edges_kernel, dim3(nb), dim3(256), 0, s, d_src, d_tgt, E, by_target, w.a);
+  AG_KERNEL("ag_pack_edges_kernel", ag_pack_edges_kernel, dim3(nb), dim3(256), s, d_src, d_tgt, E, by_target, w.a);
   AG_LAUNCH_CHECK();
   int rc = ag_sort_u64(w.temp, w.temp_bytes, w.a, w.b, E, 0, 64, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_unpack_edges_kernel, dim3(nb), dim3(256), 0, s, w.b, E, by_target, d_src, d_tgt);
+  AG_KERNEL("ag_unpack_edges_kernel", ag_unpack_edges_kernel, dim3(nb), dim3(256), s, w.b, E, by_target, d_src, d_tgt);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -214,7 +290,7 @@ extern "C" int ag_unique_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int64_
   AG_REQUIRE(E >= 0, "ag_unique_edges: negative edge count");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (E == 0) {
-    hipLaunchKernelGGL(ag_zero_i64_kernel, dim3(1), dim3(1), 0, s, d_num_unique);
+    AG_KERNEL("ag_zero_i64_kernel", ag_zero_i64_kernel, dim3(1), dim3(1), s, d_num_unique);
     AG_LAUNCH_CHECK();
     return AG_OK;
   }
@@ -223,13 +299,13 @@ extern "C" int ag_unique_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int64_
   AgSortWs w;
   ag_sort_ws_carve(c, E, &w);
   const int nb = ag_blocks(E, 256, 8192);
-  hipLaunchKernelGGL(ag_pack_edges_kernel, dim3(nb), dim3(256), 0, s, d_src, d_tgt, E, 0, w.a);
+  AG_KERNEL("ag_pack_edges_kernel", ag_pack_edges_kernel, dim3(nb), dim3(256), s, d_src, d_tgt, E, 0, w.a);
   AG_LAUNCH_CHECK();
   int rc = ag_sort_u64(w.temp, w.temp_bytes, w.a, w.b, E, 0, 64, s);
   if (rc) return rc;
   size_t tb = w.temp_bytes;
   AG_HIP(rocprim::unique(w.temp, tb, w.b, w.a, d_num_unique, static_cast<size_t>(E), rocprim::equal_to<uint64_t>(), s));
-  hipLaunchKernelGGL(ag_unpack_unique_kernel, dim3(nb), dim3(256), 0, s, w.a, d_num_unique, d_src, d_tgt);
+  AG_KERNEL("ag_unpack_unique_kernel", ag_unpack_unique_kernel, dim3(nb), dim3(256), s, w.a, d_num_unique, d_src, d_tgt);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -117,22 +117,19 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   g.inv_dlat = nb / AG_PI;
   g.ncols = ncols;
   g.off = off;
-  hipLaunchKernelGGL(ag_band_table_kernel, dim3(1), dim3(1024), 0, stream, nb, g.dlat, ncols, off);
+  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(1), dim3(1024), stream, nb, g.dlat, ncols, off);
   AG_LAUNCH_CHECK();
   const int blocks = ag_blocks(n, 256, 16384);
-  hipLaunchKernelGGL(ag_cell_key_kernel, dim3(blocks), dim3(256), 0, stream, g,
-                     reinterpret_cast<const float2*>(d_pts), n, keys_a);
+  AG_KERNEL("ag_cell_key_kernel", ag_cell_key_kernel, dim3(blocks), dim3(256), stream, g, reinterpret_cast<const float2*>(d_pts), n, keys_a);
   AG_LAUNCH_CHECK();
   int cell_bits = 1;
   while ((int64_t(1) << cell_bits) <= ncells_ub) ++cell_bits;
   int rc = ag_sort_u64(temp, temp_bytes, keys_a, keys_b, n, 32, 32 + cell_bits, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_cell_start_kernel, dim3(ag_blocks(ncells_ub + 1, 256, 16384)), dim3(256), 0, stream, keys_b, n,
-                     ncells_ub, cell_start);
+  AG_KERNEL("ag_cell_start_kernel", ag_cell_start_kernel, dim3(ag_blocks(ncells_ub + 1, 256, 16384)), dim3(256), stream, keys_b, n, ncells_ub, cell_start);
   AG_LAUNCH_CHECK();
   if (want_pts) {
-    hipLaunchKernelGGL(ag_binned_points_kernel, dim3(blocks), dim3(256), 0, stream, keys_b,
-                       reinterpret_cast<const float2*>(d_pts), n, pts);
+    AG_KERNEL("ag_binned_points_kernel", ag_binned_points_kernel, dim3(blocks), dim3(256), stream, keys_b, reinterpret_cast<const float2*>(d_pts), n, pts);
     AG_LAUNCH_CHECK();
   }
   out->grid = g;
@@ -467,7 +464,7 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
 template <int CAP>
 static void ag_launch_cell_kernel(const AgKnnArgs& a, int64_t ncells_ub, hipStream_t stream) {
   const int blocks = ag_blocks(ncells_ub, AG_WAVES_PER_BLOCK);
-  hipLaunchKernelGGL(ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), 0, stream, a);
+  AG_KERNEL("ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
 }
 
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
@@ -480,8 +477,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   AgKnnWs w;
   int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w);
   if (rc) return rc;
-  hipLaunchKernelGGL(ag_knn_init_kernel, dim3(1), dim3(64), 0, stream, w.queue_count, w.max_bits,
-                     reinterpret_cast<long long*>(d_stats));
+  AG_KERNEL("ag_knn_init_kernel", ag_knn_init_kernel, dim3(1), dim3(64), stream, w.queue_count, w.max_bits, reinterpret_cast<long long*>(d_stats));
   AG_LAUNCH_CHECK();
 
   AgKnnArgs a;
@@ -516,10 +512,10 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   else if (k + 1 <= 32) ag_launch_cell_kernel<32>(a, ncu, stream);
   else ag_launch_cell_kernel<AG_KNN_MAX_K + 1>(a, ncu, stream);
   AG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ag_knn_exact_kernel, dim3(2048), dim3(256), 0, stream, a);
+  AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
   AG_LAUNCH_CHECK();
   if (self_query) {
-    hipLaunchKernelGGL(ag_maxdist_finish_kernel, dim3(1), dim3(1), 0, stream, w.max_bits, d_out_max);
+    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1), stream, w.max_bits, d_out_max);
     AG_LAUNCH_CHECK();
   }
   return AG_OK;
@@ -722,7 +718,7 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
   a.out_src = nullptr;
   a.out_tgt = nullptr;
   if (nt > 0) {
-    hipLaunchKernelGGL(ag_radius_kernel<false>, dim3(ag_blocks(nt, 4, 8192)), dim3(256), 0, s, a);
+    AG_KERNEL("ag_radius_kernel", ag_radius_kernel<false>, dim3(ag_blocks(nt, 4, 8192)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
   return ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
@@ -745,7 +741,7 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
   a.offsets = const_cast<int64_t*>(d_offsets);
   a.out_src = d_out_src;
   a.out_tgt = d_out_tgt;
-  hipLaunchKernelGGL(ag_radius_kernel<true>, dim3(ag_blocks(nt, 4, 8192)), dim3(256), 0, s, a);
+  AG_KERNEL("ag_radius_kernel", ag_radius_kernel<true>, dim3(ag_blocks(nt, 4, 8192)), dim3(256), s, a);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

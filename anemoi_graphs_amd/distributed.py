@@ -1,0 +1,251 @@
+"""Latitude-band sharding of one graph build over the GPUs of a node (one process per GPU).
+
+The data nodes are split into ``world_size`` contiguous latitude bands of equal node count (the
+data grid must be ordered north -> south, as every generated grid and the icosphere nodes are).
+Rank r owns band r:
+
+* decoder (KNNEdges hidden -> data): targets = the rank's own data band, sources = the hidden
+  mesh, which is tiny and replicated -> no exchange;
+* encoder (CutOffEdges data -> hidden): targets = the hidden nodes whose latitude falls in the
+  band (a contiguous id range, hidden nodes are latitude-sorted), sources = the rank's data band
+  widened by the cut-off radius: the missing rows come from the two adjacent ranks (a one-hop halo
+  exchange; if the radius exceeded a whole band the bands would be all-gathered instead);
+* processor (MultiScaleEdges) and TriNodes: replicated, they are a few MB;
+* raw edge attributes are computed per shard next to the edges; the edge lists and raw attributes
+  are all-gathered (variable length, rank order = target order, so the concatenation is already in
+  the single-GPU order) and the global normalisations run on the gathered arrays.
+
+Collectives: one MAX all-reduce is avoided by replicating the reference-distance query; halo
+point-to-point send/recv with the two neighbours; all-gather of counts and of the padded edge
+chunks.  With the ``gloo`` backend (CPU tests) tensors are staged through host memory.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops as _hip_ops
+from . import settings
+from .hetero import HeteroData
+
+
+class Communicator:
+    """The three exchanges the sharded build needs, over ``torch.distributed`` (RCCL or gloo)."""
+
+    def __init__(self, dist, rank: int, world_size: int):
+        self.dist, self.rank, self.world = dist, rank, world_size
+        self.host_staged = dist is not None and dist.get_backend() == "gloo"
+
+    def _out(self, t: torch.Tensor) -> torch.Tensor:
+        return t.cpu() if self.host_staged else t
+
+    def _back(self, t: torch.Tensor, device) -> torch.Tensor:
+        return t.to(device) if self.host_staged else t
+
+    def all_gather_sizes(self, values: list[int], device) -> torch.Tensor:
+        mine = torch.tensor(values, dtype=torch.int64, device="cpu" if self.host_staged else device)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return torch.stack(out).cpu()
+
+    def all_gather_rows(self, t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        """Concatenate variable-length chunks of every rank along ``dim`` in rank order."""
+        device = t.device
+        t = t.movedim(dim, 0).contiguous()
+        counts = self.all_gather_sizes([t.shape[0]], device)[:, 0].tolist()
+        width = max(counts)
+        padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        padded[: t.shape[0]] = t
+        padded = self._out(padded)
+        chunks = [torch.empty_like(padded) for _ in range(self.world)]
+        self.dist.all_gather(chunks, padded)
+        out = torch.cat([c[:n] for c, n in zip(chunks, counts)], dim=0)
+        return self._back(out, device).movedim(0, dim).contiguous()
+
+    def exchange_halo(self, to_north: torch.Tensor, to_south: torch.Tensor):
+        """Send rows to the two neighbours, receive theirs: returns (from_north, from_south)."""
+        device = to_north.device
+        sizes = self.all_gather_sizes([to_north.shape[0], to_south.shape[0]], device)
+        n_from_north = int(sizes[self.rank - 1, 1]) if self.rank > 0 else 0
+        n_from_south = int(sizes[self.rank + 1, 0]) if self.rank < self.world - 1 else 0
+        recv_dev = "cpu" if self.host_staged else device
+        from_north = torch.empty((n_from_north, 2), dtype=to_north.dtype, device=recv_dev)
+        from_south = torch.empty((n_from_south, 2), dtype=to_north.dtype, device=recv_dev)
+        ops = []
+        P2POp = self.dist.P2POp
+        if self.rank > 0:
+            if to_north.shape[0]:
+                ops.append(P2POp(self.dist.isend, self._out(to_north.contiguous()), self.rank - 1))
+            if n_from_north:
+                ops.append(P2POp(self.dist.irecv, from_north, self.rank - 1))
+        if self.rank < self.world - 1:
+            if to_south.shape[0]:
+                ops.append(P2POp(self.dist.isend, self._out(to_south.contiguous()), self.rank + 1))
+            if n_from_south:
+                ops.append(P2POp(self.dist.irecv, from_south, self.rank + 1))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        return self._back(from_north, device), self._back(from_south, device)
+
+
+def band_bounds(n_total: int, world_size: int) -> list[int]:
+    """Equal-count contiguous bands: band r = ids [b[r], b[r+1])."""
+    return [(n_total * r) // world_size for r in range(world_size + 1)]
+
+
+class ShardedGraphBuilder:
+    """Builds the encoder / processor / decoder graph of a data grid and an icosphere of the given
+    resolution; on ``world_size`` > 1 ranks each builds its latitude band and all end with the
+    complete graph.  ``backend`` provides the search / mesh / attribute operations (default: the HIP
+    kernels in ``anemoi_graphs_amd.ops``; the CPU tests inject the oracle)."""
+
+    def __init__(self, data_x: torch.Tensor, resolution: int, cutoff_factor: float = 0.6,
+                 num_nearest_neighbours: int = 3, x_hops: int = 1, rank: int = 0, world_size: int = 1, dist=None,
+                 backend=None, attributes: bool = True, edge_length_norm: str | None = "unit-max",
+                 edge_direction_norm: str | None = None):
+        self.backend = _hip_ops if backend is None else backend
+        self.resolution = resolution
+        self.cutoff_factor = cutoff_factor
+        self.k = num_nearest_neighbours
+        self.x_hops = x_hops
+        self.rank, self.world = rank, world_size
+        self.attributes = attributes
+        self.len_norm, self.dir_norm = edge_length_norm, edge_direction_norm
+        self.n_data = int(data_x.shape[0])
+        self.bounds = band_bounds(self.n_data, world_size)
+        lo, hi = self.bounds[rank], self.bounds[rank + 1]
+        self.d_lo, self.d_hi = lo, hi
+        self.data_full = data_x if world_size == 1 else None
+        self.data_local = data_x[lo:hi].contiguous()
+        if world_size > 1:
+            lat = self.data_local[:, 0]
+            if lat.numel() > 1 and bool((lat[1:] > lat[:-1]).any()):
+                raise ValueError("latitude-band sharding needs data nodes ordered north -> south")
+            self.comm = Communicator(dist, rank, world_size)
+            # cut latitudes: the first latitude of every band (band r holds lat <= cut[r])
+            firsts = self.comm.all_gather_rows(self.data_local[:1, 0].reshape(1, 1))
+            lasts = self.comm.all_gather_rows(self.data_local[-1:, 0].reshape(1, 1))
+            self.first_lat = firsts.reshape(-1).cpu().tolist()
+            self.last_lat = lasts.reshape(-1).cpu().tolist()
+        else:
+            self.comm = None
+
+    # ---------------------------------------------------------------------------------- single GPU
+    def _build_single(self) -> HeteroData:
+        """The plain plugin sequence the orchestrator runs (create.py:78-90 of the reference)."""
+        from .edges import CutOffEdges, KNNEdges, MultiScaleEdges
+        from .edges.attributes import EdgeDirection, EdgeLength
+        from .nodes import TriNodes
+
+        graph = HeteroData()
+        graph["data"].x = self.data_full
+        graph["data"].node_type = "LatLonNodes"
+        graph = TriNodes(self.resolution, "hidden").update_graph(graph, {})
+        builders = [
+            CutOffEdges("data", "hidden", self.cutoff_factor),
+            MultiScaleEdges("hidden", "hidden", self.x_hops),
+            KNNEdges("hidden", "data", self.k),
+        ]
+        for b in builders:
+            graph = b.update_graph(graph)
+            if self.attributes:
+                graph[b.name]["edge_length"] = EdgeLength(norm=self.len_norm).compute(graph, b.name)
+                graph[b.name]["edge_dirs"] = EdgeDirection(norm=self.dir_norm).compute(graph, b.name)
+        return graph
+
+    # ---------------------------------------------------------------------------------- sharded
+    def _attrs(self, src_x, tgt_x, edge_index):
+        length, direction = self.backend.edge_attrs(src_x, tgt_x, edge_index)
+        return length.reshape(-1, 1), direction
+
+    def _finish_attrs(self, store, length, direction):
+        store["edge_length"] = self.backend.normalise_(length.contiguous(), self.len_norm)
+        store["edge_dirs"] = self.backend.normalise_(direction.contiguous(), self.dir_norm)
+
+    def _build_sharded(self) -> HeteroData:
+        be, comm, r, W = self.backend, self.comm, self.rank, self.world
+        dev = self.data_local.device
+        graph = HeteroData()
+        _xyz, _faces, hidden, order, rank_map = be.icosphere(self.resolution)
+        hidden = hidden.to(dev)
+        graph["hidden"].x = hidden
+        graph["hidden"].node_type = "TriNodes"
+        nh = hidden.shape[0]
+
+        # ---- encoder: hidden targets of my band, data sources = my band + halo
+        radius = float(be.nn_maxdist(hidden).item()) * self.cutoff_factor
+        pad = radius * 1.0e-6 + 1.0e-7
+        reach = radius + pad
+        hlat = hidden[:, 0].contiguous()
+        # hidden nodes are latitude-descending: band r = lat in (first_lat[r+1], first_lat[r]]
+        upper = float("inf") if r == 0 else self.first_lat[r]
+        lower = -float("inf") if r == W - 1 else self.first_lat[r + 1]
+        neg = (-hlat).cpu()
+        h_lo = int(torch.searchsorted(neg, torch.tensor(-upper, dtype=neg.dtype), right=False)) if r > 0 else 0
+        h_hi = int(torch.searchsorted(neg, torch.tensor(-lower, dtype=neg.dtype), right=False)) if r < W - 1 else nh
+        # rows my neighbours need from me: their hidden band widened by the reach
+        my_lat_neg = (-self.data_local[:, 0]).cpu()
+        one_hop = True
+        if r > 0:
+            # the north neighbour's targets reach down to first_lat[r] - reach
+            n_north = int(torch.searchsorted(my_lat_neg, torch.tensor(-(self.first_lat[r] - reach), dtype=my_lat_neg.dtype), right=True))
+            one_hop = one_hop and n_north < self.data_local.shape[0]
+        else:
+            n_north = 0
+        if r < W - 1:
+            # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
+            s_start = int(torch.searchsorted(my_lat_neg, torch.tensor(-(self.first_lat[r + 1] + reach), dtype=my_lat_neg.dtype), right=False))
+            one_hop = one_hop and s_start > 0
+        else:
+            s_start = self.data_local.shape[0]
+        flags = comm.all_gather_sizes([int(one_hop)], dev)[:, 0]
+        if bool(flags.min()):
+            from_north, from_south = comm.exchange_halo(self.data_local[:n_north], self.data_local[s_start:])
+            sources = torch.cat([from_north, self.data_local, from_south], dim=0).contiguous()
+            g_lo = self.d_lo - from_north.shape[0]
+        else:  # radius wider than a band: every rank takes all data rows
+            sources = comm.all_gather_rows(self.data_local)
+            g_lo = 0
+        targets = hidden[h_lo:h_hi].contiguous()
+        enc = be.radius_edges(sources, targets, radius)
+        enc_len, enc_dir = self._attrs(sources, targets, enc) if self.attributes else (None, None)
+        enc = enc.clone()
+        enc[0] += g_lo
+        enc[1] += h_lo
+
+        # ---- decoder: my data band as targets, replicated hidden sources
+        ids = be.knn(hidden, self.data_local, self.k)
+        nt = self.data_local.shape[0]
+        dec = torch.empty((2, nt * self.k), dtype=torch.int32, device=ids.device)
+        dec[0] = ids.reshape(-1)
+        dec[1] = torch.arange(nt, dtype=torch.int32, device=ids.device).repeat_interleave(self.k)
+        dec_len, dec_dir = self._attrs(hidden, self.data_local, dec) if self.attributes else (None, None)
+        dec[1] += self.d_lo
+
+        # ---- processor: replicated
+        proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map)
+
+        # ---- gather
+        graph["data"].x = comm.all_gather_rows(self.data_local)
+        graph["data"].node_type = "LatLonNodes"
+        for name, e, ln, dr, etype in (
+            (("data", "to", "hidden"), enc, enc_len, enc_dir, "CutOffEdges"),
+            (("hidden", "to", "data"), dec, dec_len, dec_dir, "KNNEdges"),
+        ):
+            graph[name].edge_index = comm.all_gather_rows(e, dim=1)
+            graph[name].edge_type = etype
+            if self.attributes:
+                self._finish_attrs(graph[name], comm.all_gather_rows(ln), comm.all_gather_rows(dr))
+        name = ("hidden", "to", "hidden")
+        graph[name].edge_index = proc
+        graph[name].edge_type = "MultiScaleEdges"
+        if self.attributes:
+            ln, dr = self._attrs(hidden, hidden, proc)
+            self._finish_attrs(graph[name], ln, dr)
+        return graph
+
+    def build(self) -> HeteroData:
+        if self.world == 1:
+            with settings.resident(settings.device_resident):
+                return self._build_single()
+        return self._build_sharded()

@@ -1,0 +1,75 @@
+"""Edge attributes with the reference's interface
+(/root/reference/src/anemoi/graphs/edges/attributes.py:24-157, normalise.py:17-55)."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import ops
+from ..hetero import HeteroData
+from ..utils import place
+
+
+class NormaliserMixin:
+    """Global normalisation of an attribute (normalise.py:20-55) on the device."""
+
+    def normalise(self, values: torch.Tensor) -> torch.Tensor:
+        return ops.normalise_(values, self.norm)
+
+
+class BaseEdgeAttribute(ABC, NormaliserMixin):
+    def __init__(self, norm: str | None = None) -> None:
+        self.norm = norm
+
+    @abstractmethod
+    def get_raw_values(self, graph: HeteroData, source_name: str, target_name: str, *args, **kwargs) -> torch.Tensor: ...
+
+    def post_process(self, values: torch.Tensor) -> torch.Tensor:
+        if values.ndim == 1:
+            values = values[:, None]
+        return place(self.normalise(values.contiguous()))
+
+    def compute(self, graph: HeteroData, edges_name: tuple[str, str, str], *args, **kwargs) -> torch.Tensor:
+        source_name, _, target_name = edges_name
+        assert (
+            source_name in graph.node_types
+        ), f"Node \"{source_name}\" not found in graph. Optional nodes are {', '.join(graph.node_types)}."
+        assert (
+            target_name in graph.node_types
+        ), f"Node \"{target_name}\" not found in graph. Optional nodes are {', '.join(graph.node_types)}."
+        values = self.get_raw_values(graph, source_name, target_name, *args, **kwargs)
+        return self.post_process(values)
+
+
+class EdgeDirection(BaseEdgeAttribute):
+    """Unit (x, y) direction of every edge, by default after rotating the target node to the north
+    pole (edges/attributes.py:56-104)."""
+
+    def __init__(self, norm: str | None = None, luse_rotated_features: bool = True) -> None:
+        super().__init__(norm)
+        self.luse_rotated_features = luse_rotated_features
+
+    def get_raw_values(self, graph: HeteroData, source_name: str, target_name: str) -> torch.Tensor:
+        edge_index = graph[(source_name, "to", target_name)].edge_index
+        _, direction = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index, want_len=False,
+                                      rotated=self.luse_rotated_features)
+        return direction
+
+
+class EdgeLength(BaseEdgeAttribute):
+    """Great-circle length of every edge in radians (edges/attributes.py:107-157)."""
+
+    def __init__(self, norm: str | None = None, invert: bool = False) -> None:
+        super().__init__(norm)
+        self.invert = invert
+
+    def get_raw_values(self, graph: HeteroData, source_name: str, target_name: str) -> torch.Tensor:
+        edge_index = graph[(source_name, "to", target_name)].edge_index
+        length, _ = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index, want_dir=False)
+        return length
+
+    def post_process(self, values: torch.Tensor) -> torch.Tensor:
+        if values.ndim == 1:
+            values = values[:, None]
+        return place(ops.normalise_(values.contiguous(), self.norm, invert=self.invert))

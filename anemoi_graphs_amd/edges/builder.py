@@ -1,0 +1,193 @@
+"""Edge builders with the reference's plugin interface
+(/root/reference/src/anemoi/graphs/edges/builder.py:42-462), running on the HIP kernels."""
+from __future__ import annotations
+
+import logging
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import ops
+from ..hetero import HeteroData, NodeStorage
+from ..instantiate import instantiate
+from ..utils import concat_edges, place
+
+LOGGER = logging.getLogger(__name__)
+EARTH_RADIUS = 6371.0  # km (/root/reference/src/anemoi/graphs/__init__.py:10)
+
+
+class BaseEdgeBuilder(ABC):
+    """Base class for edge builders (edges/builder.py:42-156)."""
+
+    def __init__(
+        self,
+        source_name: str,
+        target_name: str,
+        source_mask_attr_name: str | None = None,
+        target_mask_attr_name: str | None = None,
+    ):
+        self.source_name = source_name
+        self.target_name = target_name
+        self.source_mask_attr_name = source_mask_attr_name
+        self.target_mask_attr_name = target_mask_attr_name
+
+    @property
+    def name(self) -> tuple[str, str, str]:
+        return self.source_name, "to", self.target_name
+
+    @abstractmethod
+    def get_adjacency_matrix(self, source_nodes: NodeStorage, target_nodes: NodeStorage) -> torch.Tensor:
+        """The edges as a device int32 tensor [2, E]: row 0 source ids, row 1 target ids
+        (the reference returns a scipy COO matrix of shape (n_target, n_source) whose (col, row)
+        are exactly these two rows: edges/builder.py:84-87)."""
+
+    def prepare_node_data(self, graph: HeteroData) -> tuple[NodeStorage, NodeStorage]:
+        return graph[self.source_name], graph[self.target_name]
+
+    def get_edge_index(self, graph: HeteroData) -> torch.Tensor:
+        source_nodes, target_nodes = self.prepare_node_data(graph)
+        edge_index = self.get_adjacency_matrix(source_nodes, target_nodes)
+        return place(edge_index.to(torch.int32))
+
+    def register_edges(self, graph: HeteroData) -> HeteroData:
+        edge_index = self.get_edge_index(graph)
+        edge_type = type(self).__name__
+        if "edge_index" in graph[self.name]:
+            graph[self.name].edge_index = concat_edges(graph[self.name].edge_index, edge_index)
+            if edge_type not in graph[self.name].edge_type:
+                graph[self.name].edge_type = graph[self.name].edge_type + "," + edge_type
+            return graph
+        graph[self.name].edge_index = edge_index
+        graph[self.name].edge_type = edge_type
+        return graph
+
+    def register_attributes(self, graph: HeteroData, config: dict) -> HeteroData:
+        for attr_name, attr_config in config.items():
+            graph[self.name][attr_name] = instantiate(attr_config).compute(graph, self.name)
+        return graph
+
+    def update_graph(self, graph: HeteroData, attrs_config: dict | None = None) -> HeteroData:
+        graph = self.register_edges(graph)
+        if attrs_config is not None:
+            graph = self.register_attributes(graph, attrs_config)
+        return graph
+
+
+class NodeMaskingMixin:
+    """Masking of source/target nodes (edges/builder.py:159-193): the search runs on the compacted
+    node sets and the ids are mapped back through the compaction maps on the device."""
+
+    def get_node_coordinates(self, source_nodes: NodeStorage, target_nodes: NodeStorage):
+        dev = ops.device_of(source_nodes.x, target_nodes.x)
+        source_coords, target_coords = ops.coords(source_nodes.x, dev), ops.coords(target_nodes.x, dev)
+        self._source_ids = self._target_ids = None
+        if self.source_mask_attr_name is not None:
+            self._source_ids = ops.mask_ids(source_nodes[self.source_mask_attr_name], dev)
+            source_coords = ops.gather_coords(source_coords, self._source_ids)
+        if self.target_mask_attr_name is not None:
+            self._target_ids = ops.mask_ids(target_nodes[self.target_mask_attr_name], dev)
+            target_coords = ops.gather_coords(target_coords, self._target_ids)
+        return source_coords, target_coords
+
+    def undo_masking(self, edge_index: torch.Tensor, source_nodes: NodeStorage, target_nodes: NodeStorage):
+        if self._target_ids is not None:
+            ops.remap_ids_(edge_index[1], self._target_ids)
+        if self._source_ids is not None:
+            ops.remap_ids_(edge_index[0], self._source_ids)
+        return edge_index
+
+
+class KNNEdges(BaseEdgeBuilder, NodeMaskingMixin):
+    """k nearest source nodes of every target node (edges/builder.py:196-270)."""
+
+    def __init__(
+        self,
+        source_name: str,
+        target_name: str,
+        num_nearest_neighbours: int,
+        source_mask_attr_name: str | None = None,
+        target_mask_attr_name: str | None = None,
+    ) -> None:
+        super().__init__(source_name, target_name, source_mask_attr_name, target_mask_attr_name)
+        assert isinstance(num_nearest_neighbours, int), "Number of nearest neighbours must be an integer"
+        assert num_nearest_neighbours > 0, "Number of nearest neighbours must be positive"
+        self.num_nearest_neighbours = num_nearest_neighbours
+
+    def get_adjacency_matrix(self, source_nodes: NodeStorage, target_nodes: NodeStorage) -> torch.Tensor:
+        source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
+        assert self.num_nearest_neighbours is not None, "number of neighbors required for knn encoder"
+        LOGGER.info(
+            "Using KNN-Edges (with %d nearest neighbours) between %s and %s.",
+            self.num_nearest_neighbours, self.source_name, self.target_name,
+        )
+        k = self.num_nearest_neighbours
+        ids = ops.knn(source_coords, target_coords, k)  # [Nt, k], ascending distance
+        nt = target_coords.shape[0]
+        edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=ids.device)
+        edge_index[0] = ids.reshape(-1)
+        edge_index[1] = torch.arange(nt, dtype=torch.int32, device=ids.device).repeat_interleave(k)
+        return self.undo_masking(edge_index, source_nodes, target_nodes)
+
+
+class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
+    """All source nodes within ``cutoff_factor`` x the target grid's reference distance of every
+    target node (edges/builder.py:273-371)."""
+
+    def __init__(
+        self,
+        source_name: str,
+        target_name: str,
+        cutoff_factor: float,
+        source_mask_attr_name: str | None = None,
+        target_mask_attr_name: str | None = None,
+    ):
+        super().__init__(source_name, target_name, source_mask_attr_name, target_mask_attr_name)
+        assert isinstance(cutoff_factor, (int, float)), "Cutoff factor must be a float"
+        assert cutoff_factor > 0, "Cutoff factor must be positive"
+        self.cutoff_factor = cutoff_factor
+
+    def get_cutoff_radius(self, graph: HeteroData, mask_attr: torch.Tensor | None = None) -> float:
+        from ..utils import get_grid_reference_distance
+
+        target_nodes = graph[self.target_name]
+        mask = target_nodes[mask_attr] if mask_attr is not None else None
+        target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask)
+        return target_grid_reference_distance * self.cutoff_factor
+
+    def prepare_node_data(self, graph: HeteroData) -> tuple[NodeStorage, NodeStorage]:
+        self.radius = self.get_cutoff_radius(graph)
+        return super().prepare_node_data(graph)
+
+    def get_adjacency_matrix(self, source_nodes: NodeStorage, target_nodes: NodeStorage) -> torch.Tensor:
+        source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
+        LOGGER.info(
+            "Using CutOff-Edges (with radius = %.1f km) between %s and %s.",
+            self.radius * EARTH_RADIUS, self.source_name, self.target_name,
+        )
+        edge_index = ops.radius_edges(source_coords, target_coords, self.radius)
+        return self.undo_masking(edge_index, source_nodes, target_nodes)
+
+
+class MultiScaleEdges(BaseEdgeBuilder):
+    """Multi-scale edges between the nodes of a refined icosahedron (edges/builder.py:374-462)."""
+
+    VALID_NODES = ["TriNodes"]
+
+    def __init__(self, source_name: str, target_name: str, x_hops: int, **kwargs):
+        super().__init__(source_name, target_name)
+        assert source_name == target_name, f"{self.__class__.__name__} requires source and target nodes to be the same."
+        assert isinstance(x_hops, int), "Number of x_hops must be an integer"
+        assert x_hops > 0, "Number of x_hops must be positive"
+        self.x_hops = x_hops
+
+    def get_adjacency_matrix(self, source_nodes: NodeStorage, target_nodes: NodeStorage) -> torch.Tensor:
+        if source_nodes.node_type not in self.VALID_NODES:
+            raise ValueError(f"Invalid node type {source_nodes.node_type}")
+        mesh = source_nodes["_nx_graph"]
+        resolutions = list(source_nodes["_resolutions"])
+        return ops.multiscale_edges(mesh.resolution, resolutions, self.x_hops, mesh.rank)
+
+    def update_graph(self, graph: HeteroData, attrs_config: dict | None = None) -> HeteroData:
+        node_type = graph[self.source_name].node_type
+        assert node_type in self.VALID_NODES, f"{self.__class__.__name__} requires {','.join(self.VALID_NODES)} nodes."
+        return super().update_graph(graph, attrs_config)

@@ -1,0 +1,37 @@
+"""``_target_`` instantiation for recipe entries (the reference uses ``hydra.utils.instantiate``:
+/root/reference/src/anemoi/graphs/create.py:79,85,138; nodes/builders/base.py:77; edges/builder.py:133).
+
+Targets of the reference package (``anemoi.graphs.<...>``) are mapped onto this package so existing
+recipes run unchanged."""
+from __future__ import annotations
+
+import importlib
+
+_ALIASES = {
+    "anemoi.graphs.nodes.TriNodes": "anemoi_graphs_amd.nodes.TriNodes",
+    "anemoi.graphs.nodes.LatLonNodes": "anemoi_graphs_amd.nodes.LatLonNodes",
+    "anemoi.graphs.edges.KNNEdges": "anemoi_graphs_amd.edges.KNNEdges",
+    "anemoi.graphs.edges.CutOffEdges": "anemoi_graphs_amd.edges.CutOffEdges",
+    "anemoi.graphs.edges.MultiScaleEdges": "anemoi_graphs_amd.edges.MultiScaleEdges",
+    "anemoi.graphs.edges.attributes.EdgeLength": "anemoi_graphs_amd.edges.attributes.EdgeLength",
+    "anemoi.graphs.edges.attributes.EdgeDirection": "anemoi_graphs_amd.edges.attributes.EdgeDirection",
+}
+
+
+def resolve(target: str):
+    target = _ALIASES.get(target, target)
+    module, _, name = target.rpartition(".")
+    try:
+        return getattr(importlib.import_module(module), name)
+    except (ImportError, AttributeError) as e:
+        raise ImportError(
+            f"cannot instantiate {target!r}: only the graph-construction hot path is provided by this package "
+            f"({', '.join(sorted(_ALIASES))})"
+        ) from e
+
+
+def instantiate(config, **kwargs):
+    cfg = dict(config)
+    target = cfg.pop("_target_")
+    cfg.update(kwargs)
+    return resolve(target)(**cfg)

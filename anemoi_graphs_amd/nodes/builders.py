@@ -1,0 +1,121 @@
+"""Node builders with the reference's plugin interface
+(/root/reference/src/anemoi/graphs/nodes/builders/base.py:22-125,
+ nodes/builders/from_refined_icosahedron.py:30-106, nodes/builders/from_vectors.py:22-67)."""
+from __future__ import annotations
+
+import logging
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from .. import ops, settings
+from ..hetero import HeteroData
+from ..instantiate import instantiate
+
+LOGGER = logging.getLogger(__name__)
+
+
+class BaseNodeBuilder(ABC):
+    """Base class for node builders: coordinates go to ``graph[name].x`` in radians (base.py:22-33)."""
+
+    hidden_attributes: set[str] = set()
+
+    def __init__(self, name: str) -> None:
+        self.name = name
+        self.area_mask_builder = None
+
+    def register_nodes(self, graph: HeteroData) -> HeteroData:
+        graph[self.name].x = self.get_coordinates()
+        graph[self.name].node_type = type(self).__name__
+        return graph
+
+    def register_attributes(self, graph: HeteroData, config: dict | None = None) -> HeteroData:
+        for hidden_attr in self.hidden_attributes:
+            graph[self.name][f"_{hidden_attr}"] = getattr(self, hidden_attr)
+        for attr_name, attr_config in (config or {}).items():
+            graph[self.name][attr_name] = instantiate(attr_config).compute(graph, self.name)
+        return graph
+
+    @abstractmethod
+    def get_coordinates(self) -> torch.Tensor: ...
+
+    def reshape_coords(self, latitudes: np.ndarray, longitudes: np.ndarray) -> torch.Tensor:
+        """Degrees -> float32 radians [N, 2] (base.py:84-101)."""
+        coords = np.stack([latitudes, longitudes], axis=-1).reshape((-1, 2))
+        coords = np.deg2rad(coords)
+        return torch.tensor(coords, dtype=torch.float32)
+
+    def update_graph(self, graph: HeteroData, attrs_config: dict | None = None) -> HeteroData:
+        graph = self.register_nodes(graph)
+        if attrs_config is None:  # as the reference: hidden attributes only with a config (base.py:120-123)
+            return graph
+        return self.register_attributes(graph, attrs_config)
+
+
+class LatLonNodes(BaseNodeBuilder):
+    """Nodes from latitude/longitude vectors in degrees (nodes/builders/from_vectors.py:22-67)."""
+
+    def __init__(self, latitudes, longitudes, name: str) -> None:
+        super().__init__(name)
+        self.latitudes = np.asarray(latitudes)
+        self.longitudes = np.asarray(longitudes)
+        assert len(self.latitudes) == len(self.longitudes), "Lenght of latitudes and longitudes must match."
+        assert self.latitudes.ndim == 1 or self.latitudes.shape[1] == 1, "latitudes must have shape (N, ) or (N, 1)."
+        assert self.longitudes.ndim == 1 or self.longitudes.shape[1] == 1, "longitudes must have shape (N, ) or (N, 1)."
+
+    def get_coordinates(self) -> torch.Tensor:
+        x = self.reshape_coords(self.latitudes, self.longitudes)
+        return x.to(ops.device_of()) if settings.device_resident else x
+
+
+class IcosahedralMesh:
+    """What ``_nx_graph`` is in the reference (the node set of the mesh, kept for MultiScaleEdges):
+    here the device-side description of the icosphere -- node<->vertex permutations -- instead of a
+    networkx graph.  ``number_of_nodes`` and ``nodes`` keep the two accessors callers use."""
+
+    def __init__(self, resolution: int, order: torch.Tensor, rank: torch.Tensor):
+        self.resolution = resolution
+        self.order = order  # node -> vertex (int32, device)
+        self.rank = rank    # vertex -> node (int32, device)
+
+    def number_of_nodes(self) -> int:
+        return int(self.order.numel())
+
+    @property
+    def nodes(self) -> list[int]:
+        return self.order.cpu().tolist()
+
+
+class IcosahedralNodes(BaseNodeBuilder, ABC):
+    """Nodes of a refined icosahedron (from_refined_icosahedron.py:30-69)."""
+
+    def __init__(self, resolution: int | list[int], name: str) -> None:
+        if isinstance(resolution, int):
+            self.resolutions = list(range(resolution + 1))
+        else:
+            self.resolutions = resolution
+        super().__init__(name)
+        self.hidden_attributes = BaseNodeBuilder.hidden_attributes | {
+            "resolutions", "nx_graph", "node_ordering", "area_mask_builder",
+        }
+
+    def get_coordinates(self) -> torch.Tensor:
+        self.nx_graph, coords_rad, self.node_ordering = self.create_nodes()
+        return coords_rad
+
+    @abstractmethod
+    def create_nodes(self): ...
+
+
+class TriNodes(IcosahedralNodes):
+    """Icosphere nodes (from_refined_icosahedron.py:99-106 -> generate/tri_icosahedron.py:24-58),
+    built by the HIP subdivision kernels.  Node order: latitude descending, ties longitude
+    descending (what generate/utils.py:30-32 produces when its two sorts are stable)."""
+
+    def create_nodes(self):
+        resolution = max(self.resolutions)
+        _xyz, _faces, latlon, order, rank = ops.icosphere(resolution)
+        mesh = IcosahedralMesh(resolution, order, rank)
+        coords = latlon if settings.device_resident else latlon.cpu()
+        return mesh, coords, order.cpu().tolist() if not settings.device_resident else order

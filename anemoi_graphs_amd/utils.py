@@ -1,0 +1,41 @@
+"""Counterparts of ``anemoi.graphs.utils`` (/root/reference/src/anemoi/graphs/utils.py) on the GPU."""
+from __future__ import annotations
+
+import torch
+
+from . import ops, settings
+
+
+def place(t: torch.Tensor, like: torch.Tensor | None = None) -> torch.Tensor:
+    """Put a result tensor where graph tensors live (host memory unless ``settings.device_resident``)."""
+    if settings.device_resident:
+        return t
+    return t.cpu()
+
+
+def get_grid_reference_distance(coords_rad: torch.Tensor, mask: torch.Tensor | None = None) -> float:
+    """Maximum over the nodes of the distance to the nearest other node (utils.py:44-63).
+
+    As in the reference the mask is only checked for shape, never applied (utils.py:32-39)."""
+    assert mask is None or mask.shape == (coords_rad.shape[0], 1), (
+        "Mask must have the same shape as the number of nodes."
+    )
+    return float(ops.nn_maxdist(coords_rad).item())
+
+
+def concat_edges(edge_indices1: torch.Tensor, edge_indices2: torch.Tensor) -> torch.Tensor:
+    """Union of two edge lists, columns unique and sorted by (source, target) (utils.py:66-81)."""
+    dev = ops.device_of(edge_indices1, edge_indices2)
+    cat = torch.cat([edge_indices1.to(dev), edge_indices2.to(dev)], dim=1)
+    out = ops.unique_edges(cat.to(torch.int32))
+    out = out.to(edge_indices1.dtype)
+    return out if edge_indices1.is_cuda else out.cpu()
+
+
+def haversine_distance(source_coords: torch.Tensor, target_coords: torch.Tensor) -> torch.Tensor:
+    """Row-wise great-circle angle in radians, float32 (utils.py:84-103)."""
+    dev = ops.device_of(source_coords, target_coords)
+    n = source_coords.shape[0]
+    idx = torch.arange(n, dtype=torch.int32, device=dev)
+    length, _ = ops.edge_attrs(source_coords, target_coords, torch.stack([idx, idx]), want_dir=False)
+    return length if torch.as_tensor(source_coords).is_cuda else length.cpu()

@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the graph-construction hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" builds the whole graph of the workload from node coordinates that are already
+resident in HBM: TriNodes(r) hidden mesh, CutOffEdges(0.6) encoder data->hidden,
+MultiScaleEdges(x_hops=1) processor hidden->hidden, KNNEdges(3) decoder hidden->data, and
+EdgeLength + EdgeDirection for the three edge sets.  Default workload: O1280 (6,599,680 nodes)
+-> icosphere r7 (163,842 nodes), the configuration the headline metric is quoted on.
+
+Prints ONE JSON line (rank 0).  ``value`` = edges of the finished graph / wall time, in Medges/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from anemoi_graphs_amd import grids, ops, profiling, settings  # noqa: E402
+from anemoi_graphs_amd.distributed import ShardedGraphBuilder  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+WORKLOADS = {
+    # name: (data grid, hidden resolution)
+    "o1280_r7": ("o1280", 7),
+    "era5_r6": ("era5", 6),
+    "o96_r4": ("o96", 4),
+}
+CUTOFF_FACTOR = 0.6
+KNN_K = 3
+X_HOPS = 1
+
+
+def algorithmic_bytes(kernel: str, sizes: dict) -> float:
+    """Compulsory HBM traffic per launch: float32 coordinates (8 B/node), int32 edge ids
+    (8 B/edge); attributes read edge_index, gather both endpoints, write length + direction."""
+    nd, nh = sizes["n_data"], sizes["n_hidden"]
+    if kernel == "ag_knn_cell_kernel":
+        return 8.0 * nh + 8.0 * nd + 8.0 * KNN_K * nd
+    if kernel == "ag_radius_kernel":
+        return 8.0 * nd + 8.0 * nh + 8.0 * sizes["e_enc"]
+    if kernel == "ag_edge_attrs_kernel":
+        return 36.0 * sizes["e_total"] / 3.0  # three launches (one per edge set); average launch
+    return 0.0
+
+
+def cpu_baseline(data: np.ndarray, hidden: np.ndarray) -> dict:
+    """The reference's CPU path (scikit-learn, called as the reference calls it) on a bounded
+    sample of the same workload, timed on this machine's host cores."""
+    from oracle import reference_path as rp
+
+    n_dec = min(len(data), 150_000)
+    n_enc = min(len(hidden), 16_384)
+    lo = (len(data) - n_dec) // 2
+    t0 = time.perf_counter()
+    e_dec = rp.knn_edges(hidden, data[lo:lo + n_dec], KNN_K)
+    t1 = time.perf_counter()
+    radius = rp.cutoff_radius(hidden, CUTOFF_FACTOR)
+    lo_h = (len(hidden) - n_enc) // 2
+    e_enc = rp.radius_edges(data, hidden[lo_h:lo_h + n_enc], radius)
+    t2 = time.perf_counter()
+    edges = e_dec.shape[1] + e_enc.shape[1]
+    return {
+        "value": round(edges / (t2 - t0) / 1e6, 4),
+        "unit": "Medges/s",
+        "cores": rp.N_JOBS,
+        "host_cpus": os.cpu_count(),
+        "kind": "port",
+        "sample": (
+            f"scikit-learn NearestNeighbors(haversine, n_jobs={rp.N_JOBS}) as the reference calls it: "
+            f"KNN k={KNN_K} decoder for {n_dec} of {len(data)} data nodes ({t1 - t0:.1f} s) + reference distance "
+            f"and CutOff encoder for {n_enc} of {len(hidden)} hidden nodes over all data nodes ({t2 - t1:.1f} s); "
+            f"{edges} edges, tree builds included"
+        ),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="o1280_r7", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist = None
+
+    grid_name, resolution = WORKLOADS[args.workload]
+    data_np = grids.named(grid_name)
+    data = torch.from_numpy(data_np).to(device)
+
+    builder = ShardedGraphBuilder(
+        data, resolution, cutoff_factor=CUTOFF_FACTOR, num_nearest_neighbours=KNN_K, x_hops=X_HOPS,
+        rank=rank, world_size=world, dist=dist,
+    )
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with settings.resident(True):
+        graph = None
+        for _ in range(args.warmup):
+            graph = builder.build()
+        barrier()
+        profiling.enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph = builder.build()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = profiling.collect()  # {kernel: (launches, total ms)} over the timed region
+        profiling.enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    e_enc = int(graph[("data", "to", "hidden")].edge_index.shape[1])
+    e_proc = int(graph[("hidden", "to", "hidden")].edge_index.shape[1])
+    e_dec = int(graph[("hidden", "to", "data")].edge_index.shape[1])
+    e_total = e_enc + e_proc + e_dec
+    sizes = {"n_data": len(data_np), "n_hidden": int(graph["hidden"].x.shape[0]), "e_enc": e_enc,
+             "e_total": e_total}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    # dominant kernel of the timed region, by total device time (HIP events on the launch stream)
+    roofline = None
+    if kernel_ms:
+        name, (launches, total_ms) = max(kernel_ms.items(), key=lambda kv: kv[1][1])
+        avg_ms = total_ms / max(launches, 1)
+        nbytes = algorithmic_bytes(name, sizes)
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": nbytes,
+            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kernel_ms.items())},
+        }
+
+    out = {
+        "metric": "Medges/s, full graph build (TriNodes + CutOff encoder + MultiScale processor + KNN decoder + edge attributes)",
+        "value": round(e_total / (elapsed / args.steps) / 1e6, 3),
+        "unit": "Medges/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 filter + f64 haversine ranking, int32 ids",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{grid_name.upper()} ({sizes['n_data']} nodes) -> icosphere r{resolution} "
+                        f"({sizes['n_hidden']} nodes): CutOff {CUTOFF_FACTOR} encoder {e_enc} edges, MultiScale "
+                        f"x_hops={X_HOPS} processor {e_proc} edges, KNN k={KNN_K} decoder {e_dec} edges, "
+                        f"EdgeLength+EdgeDirection on all",
+            "edges": e_total,
+            "parallelism": "single GPU" if world == 1 else f"latitude bands x{world}",
+        },
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        hidden_np = graph["hidden"].x.cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(data_np, hidden_np)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

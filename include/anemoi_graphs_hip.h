@@ -36,6 +36,14 @@ extern "C" {
 const char* ag_last_error(void);
 int ag_version(void);
 
+/* Per-kernel timing (no counterpart in the reference).  While enabled, every kernel launch of
+ * the library is bracketed by HIP events recorded on the launch stream.  ag_profile_collect
+ * synchronises on those events and writes one line per kernel name, "<name> <launches>
+ * <total_ms>\n", into buf (NUL-terminated, truncated to buf_bytes); returns the untruncated
+ * length.  ag_profile_enable(0|1) also discards what was recorded so far. */
+int ag_profile_enable(int on);
+int ag_profile_collect(char* buf, size_t buf_bytes);
+
 /* ---------------------------------------------------------------------------------------
  * k nearest neighbours on the sphere.
  * Replaces NearestNeighbors(metric="haversine").fit(src).kneighbors_graph(tgt, k, "distance")
