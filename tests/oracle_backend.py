@@ -1,0 +1,57 @@
+"""The operations interface of ``anemoi_graphs_amd.ops`` implemented with the CPU oracle, so that the
+host-side logic (sharding, gathering, re-indexing) can be tested without a GPU.  Test infrastructure."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import icosphere as ico
+from oracle import reference_path as rp
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def icosphere(resolution, device=None):
+    v, f = ico.icosphere(resolution)
+    coords = ico.latlon_rad(v)
+    order = rp.coordinates_ordering_canonical(coords)
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    return (torch.from_numpy(v), torch.from_numpy(f.astype(np.int32)), torch.from_numpy(coords[order].copy()),
+            torch.from_numpy(order.astype(np.int32)), torch.from_numpy(rank.astype(np.int32)))
+
+
+def nn_maxdist(x):
+    return torch.tensor(rp.grid_reference_distance(_np(x)), dtype=torch.float64)
+
+
+def radius_edges(src, tgt, radius, sort=True):
+    e = rp.radius_edges(_np(src), _np(tgt), radius)
+    return torch.from_numpy(np.ascontiguousarray(rp.canonical_sort(e)))
+
+
+def knn(src, tgt, k):
+    e = rp.knn_edges(_np(src), _np(tgt), k)
+    return torch.from_numpy(e[0].reshape(len(_np(tgt)), k).copy())
+
+
+def multiscale_edges(max_resolution, levels, x_hops, rank, active=None):
+    rank = _np(rank)
+    order = np.empty_like(rank)
+    order[rank] = np.arange(len(rank))
+    e = rp.multiscale_edges(list(levels), x_hops, order)
+    return torch.from_numpy(np.ascontiguousarray(rp.canonical_sort(e)))
+
+
+def edge_attrs(src_x, tgt_x, edge_index, want_len=True, want_dir=True, rotated=True):
+    s, t, e = _np(src_x), _np(tgt_x), _np(edge_index)
+    length = torch.from_numpy(rp.edge_lengths(s, t, e).astype(np.float32)) if want_len else None
+    direction = torch.from_numpy(rp.edge_directions(s, t, e, rotated).astype(np.float32)) if want_dir else None
+    return length, direction
+
+
+def normalise_(values, norm, invert=False):
+    out = rp.post_process(_np(values), norm, invert)
+    return torch.from_numpy(np.ascontiguousarray(out))

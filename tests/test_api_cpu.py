@@ -1,0 +1,135 @@
+"""CPU: host-side behaviour of the plugin classes, mirroring the reference's own tests
+(/root/reference/tests/edges/test_knn.py, test_cutoff.py, test_multiscale_edges.py,
+tests/test_normaliser.py, tests/test_create.py) where they do not need the device."""
+import pytest
+import torch
+
+from anemoi_graphs_amd import ops
+from anemoi_graphs_amd.create import DotDict, GraphCreator
+from anemoi_graphs_amd.edges import CutOffEdges, KNNEdges, MultiScaleEdges
+from anemoi_graphs_amd.edges.attributes import EdgeDirection, EdgeLength
+from anemoi_graphs_amd.hetero import HeteroData
+from anemoi_graphs_amd.instantiate import instantiate, resolve
+from anemoi_graphs_amd.nodes import LatLonNodes, TriNodes
+
+
+def test_knn_init():
+    assert isinstance(KNNEdges("test_nodes1", "test_nodes2", 3), KNNEdges)
+    assert KNNEdges("a", "b", 3).name == ("a", "to", "b")
+
+
+@pytest.mark.parametrize("num_nearest_neighbours", [-1, 2.6, "hello", None])
+def test_knn_fail_init(num_nearest_neighbours):
+    with pytest.raises(AssertionError):
+        KNNEdges("test_nodes1", "test_nodes2", num_nearest_neighbours)
+
+
+def test_cutoff_init():
+    assert isinstance(CutOffEdges("test_nodes1", "test_nodes2", 0.5), CutOffEdges)
+
+
+@pytest.mark.parametrize("cutoff_factor", [-0.5, "hello", None])
+def test_cutoff_fail_init(cutoff_factor):
+    with pytest.raises(AssertionError):
+        CutOffEdges("test_nodes1", "test_nodes2", cutoff_factor)
+
+
+def test_multiscale_init():
+    assert isinstance(MultiScaleEdges("test_nodes", "test_nodes", 1), MultiScaleEdges)
+
+
+@pytest.mark.parametrize("x_hops", [-0.5, "hello", None, -4])
+def test_multiscale_fail_init(x_hops):
+    with pytest.raises(AssertionError):
+        MultiScaleEdges("test_nodes", "test_nodes", x_hops)
+
+
+def test_multiscale_fail_init_diff_nodes():
+    with pytest.raises(AssertionError):
+        MultiScaleEdges("test_nodes", "test_nodes2", 0)
+
+
+def test_multiscale_rejects_foreign_node_type():
+    graph = HeteroData()
+    graph["fail_nodes"].x = [1, 2, 3]
+    graph["fail_nodes"].node_type = "FailNodes"
+    with pytest.raises(AssertionError):
+        MultiScaleEdges("fail_nodes", "fail_nodes", 1).update_graph(graph)
+
+
+def test_attribute_requires_known_nodes():
+    graph = HeteroData()
+    graph["test_nodes"].x = torch.zeros((4, 2))
+    with pytest.raises(AssertionError):
+        EdgeLength().compute(graph, ("test_nodes", "to", "unknown_nodes"))
+    with pytest.raises(AssertionError):
+        EdgeDirection().compute(graph, ("unknown_nodes", "to", "test_nodes"))
+
+
+def test_invalid_norm_is_a_value_error():
+    with pytest.raises(ValueError):
+        ops.normalise_(torch.zeros(3), "invalid")
+
+
+def test_targets_of_the_reference_package_resolve_here():
+    assert resolve("anemoi.graphs.edges.KNNEdges") is KNNEdges
+    assert resolve("anemoi.graphs.nodes.TriNodes") is TriNodes
+    assert resolve("anemoi.graphs.edges.attributes.EdgeLength") is EdgeLength
+    b = instantiate({"_target_": "anemoi.graphs.edges.CutOffEdges", "cutoff_factor": 0.6}, source_name="a", target_name="b")
+    assert isinstance(b, CutOffEdges) and b.cutoff_factor == 0.6
+    with pytest.raises(ImportError):
+        resolve("anemoi.graphs.nodes.HexNodes")
+
+
+def test_resolution_list_and_hidden_attributes():
+    assert TriNodes(3, "h").resolutions == [0, 1, 2, 3]
+    assert TriNodes([0, 2], "h").resolutions == [0, 2]
+    assert {"resolutions", "nx_graph", "node_ordering", "area_mask_builder"} <= TriNodes(1, "h").hidden_attributes
+
+
+def test_latlon_nodes_shape_checks():
+    with pytest.raises(AssertionError):
+        LatLonNodes([0.0, 1.0], [0.0], "n")
+    x = LatLonNodes([0.0, 90.0], [0.0, 180.0], "n").reshape_coords(
+        torch.tensor([0.0, 90.0]).numpy(), torch.tensor([0.0, 180.0]).numpy())
+    assert x.dtype == torch.float32 and x.shape == (2, 2)
+    assert x[1, 0].item() == pytest.approx(torch.pi / 2)
+
+
+def test_graph_creator_legacy_edge_builder_key():
+    cfg = {
+        "nodes": {},
+        "edges": [{
+            "source_name": "a", "target_name": "b",
+            "edge_builder": {"_target_": "anemoi.graphs.edges.KNNEdges", "num_nearest_neighbours": 3},
+            "source_mask_attr_name": "m",
+        }],
+    }
+    with pytest.warns(DeprecationWarning):
+        creator = GraphCreator(cfg)
+    eb = creator.config.edges[0].edge_builders
+    assert len(eb) == 1 and eb[0].source_mask_attr_name == "m" and eb[0].target_mask_attr_name is None
+
+
+def test_clean_removes_private_attributes():
+    graph = HeteroData()
+    graph["n"].x = torch.zeros((2, 2))
+    graph["n"]["_hidden"] = 1
+    graph[("n", "to", "n")].edge_index = torch.zeros((2, 1), dtype=torch.int32)
+    graph[("n", "to", "n")]["_tmp"] = 2
+    graph = GraphCreator({"nodes": {}, "edges": []}).clean(graph)
+    assert "_hidden" not in graph["n"] and "_tmp" not in graph[("n", "to", "n")] and "x" in graph["n"]
+
+
+def test_dotdict():
+    d = DotDict({"a": {"b": [{"c": 1}]}})
+    assert d.a.b[0].c == 1
+
+
+def test_no_silent_fallback_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.knn(torch.zeros((4, 2)), torch.zeros((4, 2)), 1)
+    with pytest.raises(RuntimeError):
+        TriNodes(1, "h").update_graph(HeteroData(), {})

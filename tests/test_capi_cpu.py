@@ -1,0 +1,46 @@
+"""CPU: the shared library loads, exports every symbol the header declares, the ctypes table mirrors
+the header, and argument validation (which runs before any HIP call) reports errors."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from anemoi_graphs_amd import _lib
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "anemoi_graphs_hip.h").read_text()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(ag_[a-z0-9_]+)\s*\(", body)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    names = declared_functions()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    assert lib.ag_version() >= 100
+    rc = lib.ag_knn(None, 10, None, 5, 0, None, None, None, None, 0, None)
+    assert rc == -1 and b"k=0" in lib.ag_last_error()
+    rc = lib.ag_knn(None, 2, None, 5, 3, None, None, None, None, 0, None)
+    assert rc == -1 and b"exceeds" in lib.ag_last_error()
+    assert lib.ag_nn_maxdist(None, 1, None, None, 0, None) == -1
+    assert lib.ag_normalise(None, 10, 9, 0, None, 0, None) == -1
+    v, f = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.ag_icosphere_sizes(7, ctypes.byref(v), ctypes.byref(f)) == 0
+    assert (v.value, f.value) == (163842, 327680)
+    assert lib.ag_icosphere_sizes(12, ctypes.byref(v), ctypes.byref(f)) == -1
+    with pytest.raises(_lib.LibraryError):
+        _lib.check(lib.ag_icosphere_sizes(-1, None, None), "ag_icosphere_sizes")

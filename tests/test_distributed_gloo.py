@@ -1,0 +1,88 @@
+"""CPU, two processes over gloo: the latitude-band sharded build (halo exchange, per-band queries,
+variable-length all-gather, re-indexing) yields exactly the single-process graph.  The search and
+attribute operations are played by the CPU oracle here; the sharding logic is what is under test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from anemoi_graphs_amd import grids
+from anemoi_graphs_amd.distributed import ShardedGraphBuilder, band_bounds
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(data, rank, world, d, resolution, factor):
+    from tests import oracle_backend
+
+    b = ShardedGraphBuilder(torch.from_numpy(data), resolution, cutoff_factor=factor, num_nearest_neighbours=3,
+                            x_hops=1, rank=rank, world_size=world, dist=d, backend=oracle_backend,
+                            edge_length_norm="unit-max", edge_direction_norm="unit-std")
+    return b._build_sharded() if world > 1 else None
+
+
+def _worker(rank, world, port, grid, resolution, factor, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = grids.named(grid)
+        g = _build(data, rank, world, dist, resolution, factor)
+        out = {}
+        for name in (("data", "to", "hidden"), ("hidden", "to", "data"), ("hidden", "to", "hidden")):
+            key = "_".join(name)
+            out[key] = g[name].edge_index.numpy()
+            out[key + "_len"] = g[name]["edge_length"].numpy()
+            out[key + "_dir"] = g[name]["edge_dirs"].numpy()
+        out["data_x"] = g["data"].x.numpy()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _single(grid, resolution, factor):
+    from oracle import reference_path as rp
+    from tests import oracle_backend as ob
+
+    data = grids.named(grid)
+    _, _, hidden, order, rank = ob.icosphere(resolution)
+    hidden_np = hidden.numpy()
+    radius = rp.cutoff_radius(hidden_np, factor)
+    enc = rp.canonical_sort(rp.radius_edges(data, hidden_np, radius))
+    dec = rp.knn_edges(hidden_np, data, 3)
+    proc = rp.canonical_sort(rp.multiscale_edges(list(range(resolution + 1)), 1, order.numpy()))
+    out = {}
+    for key, e, s, t in (("data_to_hidden", enc, data, hidden_np), ("hidden_to_data", dec, hidden_np, data),
+                         ("hidden_to_hidden", proc, hidden_np, hidden_np)):
+        out[key] = e
+        out[key + "_len"] = rp.post_process(rp.edge_lengths(s, t, e), "unit-max")
+        out[key + "_dir"] = rp.post_process(rp.edge_directions(s, t, e), "unit-std")
+    out["data_x"] = data
+    return out
+
+
+@pytest.mark.parametrize("grid,resolution,factor,world", [("o16", 2, 0.6, 2), ("reg10.0", 1, 0.6, 2), ("o16", 2, 4.0, 2)])
+def test_sharded_build_equals_single(tmp_path, grid, resolution, factor, world):
+    """Third case: a radius wider than a band forces the all-gather fallback instead of the halo."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path)), nprocs=world, join=True)
+    want = _single(grid, resolution, factor)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for key, value in want.items():
+            if key.endswith("_len") or key.endswith("_dir"):
+                np.testing.assert_allclose(got[key], value, rtol=1e-6, atol=1e-7, err_msg=f"rank {r} {key}")
+            else:
+                assert np.array_equal(got[key], value), f"rank {r} {key}"
+
+
+def test_band_bounds():
+    assert band_bounds(10, 3) == [0, 3, 6, 10]
+    assert band_bounds(6599680, 8)[-1] == 6599680

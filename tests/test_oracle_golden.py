@@ -1,0 +1,108 @@
+"""CPU: the oracle (oracle/reference_path.py) reproduces the outputs the UNMODIFIED reference classes
+produced in the build container (tests/golden/*.npz, written by oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from anemoi_graphs_amd import grids
+from oracle import reference_path as rp
+from tests import helpers as h
+
+NORMS = [None, "l1", "l2", "unit-max", "unit-range", "unit-std"]
+
+
+def _tag(norm):
+    return "none" if norm is None else norm.replace("-", "_")
+
+
+def test_knn_and_cutoff_random(golden):
+    g = golden("random_sphere")
+    for k in (1, 3, 8):
+        assert np.array_equal(rp.knn_edges(g["src"], g["tgt"], k), g[f"knn{k}_edge_index"])
+    for f, tag in ((0.6, "06"), (1.3, "13")):
+        e, radius = rp.cutoff_edges(g["tgt"], g["src"], f)
+        assert radius == float(g[f"cutoff{tag}_radius"])
+        assert np.array_equal(h.canonical(e), h.canonical(g[f"cutoff{tag}_edge_index"]))
+    assert rp.grid_reference_distance(g["src"]) == float(g["refdist_src"])
+
+
+def test_masks(golden):
+    g = golden("masks")
+    s, t = rp.apply_mask(g["src"], g["src_mask"]), rp.apply_mask(g["tgt"], g["tgt_mask"])
+    e = rp.undo_masking(rp.knn_edges(s, t, 4), g["src_mask"], g["tgt_mask"])
+    assert np.array_equal(e, g["knn4_edge_index"])
+    # CutOffEdges computes the radius on ALL target nodes (edges/builder.py:338, mask_attr never passed)
+    radius = rp.cutoff_radius(g["src"], 0.8)
+    assert radius == float(g["cutoff08_radius"])
+    e = rp.undo_masking(rp.radius_edges(t, s, radius), g["tgt_mask"], g["src_mask"])
+    assert np.array_equal(h.canonical(e), h.canonical(g["cutoff08_edge_index"]))
+
+
+@pytest.mark.parametrize("case,src_key,tgt_key,prefix,ekey", [
+    ("random_sphere", "src", "tgt", "knn3_", "knn3_edge_index"),
+    ("random_sphere", "tgt", "src", "cutoff06_", "cutoff06_edge_index"),
+    ("conftest_grid", "x", "x", "knn3_", "knn3_edge_index"),
+    ("conftest_grid_f32", "x", "x", "knn3_", "knn3_edge_index"),
+])
+def test_attributes(golden, case, src_key, tgt_key, prefix, ekey):
+    g = golden(case)
+    src, tgt, e = g[src_key], g[tgt_key], g[ekey]
+    for norm in NORMS:
+        np.testing.assert_array_equal(rp.post_process(rp.edge_lengths(src, tgt, e), norm), g[f"{prefix}len_{_tag(norm)}"])
+        np.testing.assert_array_equal(rp.post_process(rp.edge_directions(src, tgt, e), norm), g[f"{prefix}dir_{_tag(norm)}"])
+    np.testing.assert_array_equal(rp.post_process(rp.edge_lengths(src, tgt, e), "unit-max", True), g[f"{prefix}len_inv_unit_max"])
+    np.testing.assert_array_equal(rp.post_process(rp.edge_directions(src, tgt, e, False), None), g[f"{prefix}dir_plain_none"])
+
+
+def test_concat_edges(golden):
+    g = golden("concat_edges")
+    assert np.array_equal(rp.concat_edges(g["e1"], g["e2"]), g["e12"])
+    assert rp.concat_edges(g["e1"], g["e2"]).tolist() == [[0, 1, 2, 3, 4], [-1, -2, -3, -4, -5]]  # tests/test_utils.py:17
+    assert np.array_equal(rp.concat_edges(g["r1"], g["r2"]), g["r12"])
+
+
+def _relabel(x_ref, edge_ref, x_mine):
+    lut = {(float(a), float(b)): i for i, (a, b) in enumerate(x_mine)}
+    m = np.array([lut[(float(a), float(b))] for a, b in x_ref])
+    return m[edge_ref]
+
+
+@pytest.mark.parametrize("r,hops", [(0, 1), (1, 1), (2, 1), (2, 2), (3, 1), (3, 3)])
+def test_tri_nodes_and_multiscale(golden, r, hops):
+    """The reference orders equal-latitude nodes arbitrarily (unstable sorts); same node SET, and the
+    same edges once the reference's nodes are matched to the canonical order by coordinates."""
+    g = golden("tri_multiscale")
+    x, order = rp.tri_nodes(r)
+    ref_x = g[f"r{r}_x"]
+    assert x.shape == ref_x.shape
+    assert np.array_equal(x[np.lexsort((x[:, 1], x[:, 0]))], ref_x[np.lexsort((ref_x[:, 1], ref_x[:, 0]))])
+    assert np.array_equal(ref_x[:, 0], x[:, 0])  # latitudes descend identically
+    e = rp.multiscale_edges(list(range(r + 1)), hops, order)
+    want = _relabel(ref_x, g[f"r{r}_h{hops}_edge_index"], x)
+    assert np.array_equal(h.canonical(e), h.canonical(want))
+
+
+def test_reference_ordering_restated(golden):
+    g = golden("tri_multiscale")
+    from oracle import icosphere as ico
+
+    for r in (0, 1, 2, 3):
+        coords = ico.latlon_rad(ico.icosphere(r)[0])
+        assert np.array_equal(rp.coordinates_ordering_reference(coords), g[f"r{r}_node_ordering"])
+
+
+def test_documented_counts():
+    """docs/_static/hetero_data_graph.txt:12-29 of the reference: O96 <-> TriNodes(5)."""
+    data = grids.octahedral(96)
+    assert data.shape == (40320, 2)
+    hidden, order = rp.tri_nodes(5)
+    assert hidden.shape == (10242, 2)
+    e, _ = rp.cutoff_edges(data, hidden, 0.6)
+    assert e.shape[1] == 62980
+    assert rp.multiscale_edges(list(range(4)), 1, rp.tri_nodes(3)[1]).shape[1] == 5100
+
+
+def test_grids():
+    assert grids.octahedral(1280).shape == (6599680, 2)
+    assert grids.regular(0.25).shape == (1038240, 2)
+    x = grids.octahedral(8)
+    assert np.all(np.diff(x[:, 0]) <= 0)
