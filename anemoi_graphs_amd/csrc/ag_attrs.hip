@@ -12,37 +12,9 @@
 //    FMA-capable x86.  Arguments are latitudes/longitudes (|x| << 71476, the range of that path).
 //  * float32 products, sums and square roots are single IEEE operations (the library is built
 //    with -ffp-contract=off).  atan2 is evaluated in float64 and rounded once.
-//  * the rotation follows scipy's Rotation.from_rotvec(...).apply(...) in float64: rotation
-//    vector -> unit quaternion -> matrix -> product.
+//  * the rotation follows scipy's Rotation.from_rotvec(...).apply(...) in float64: unit
+//    quaternion -> matrix -> product (the quaternion is formed with half-angle identities).
 #include "ag_common.hpp"
-
-__device__ __forceinline__ void ag_np_sincos_f32(float x, float* s_out, float* c_out) {
-  const float two_over_pi = 0x1.45f306p-1f;
-  const float magic = 0x1.8p+23f;
-  float q = x * two_over_pi;
-  q = (q + magic) - magic;  // round to nearest integer
-  float r = __fmaf_rn(q, -0x1.921fb0p+00f, x);
-  r = __fmaf_rn(q, -0x1.5110b4p-22f, r);
-  r = __fmaf_rn(q, -0x1.846988p-48f, r);
-  const float r2 = r * r;
-  float sp = __fmaf_rn(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
-  sp = __fmaf_rn(sp, r2, 0x1.11119ap-07f);
-  sp = __fmaf_rn(sp, r2, -0x1.555556p-03f);
-  sp = __fmaf_rn(sp, r2, 0.0f);
-  sp = __fmaf_rn(sp, r, r);
-  float cp = __fmaf_rn(0x1.98e616p-16f, r2, -0x1.6c06dcp-10f);
-  cp = __fmaf_rn(cp, r2, 0x1.55553cp-05f);
-  cp = __fmaf_rn(cp, r2, -0x1.000000p-01f);
-  cp = __fmaf_rn(cp, r2, 1.0f);
-  const int iq = static_cast<int>(rintf(q));
-  float s = (iq & 1) ? cp : sp;
-  if (iq & 2) s = 0.0f - s;
-  const int ic = iq + 1;
-  float c = (ic & 1) ? cp : sp;
-  if (ic & 2) c = 0.0f - c;
-  *s_out = s;
-  *c_out = c;
-}
 
 __device__ __forceinline__ float ag_np_sin_f32(float x) {
   float s, c;
@@ -92,19 +64,14 @@ __device__ __forceinline__ void ag_edge_direction(float2 sp, float2 tp, float* o
     vy = -static_cast<double>(txf);
     n2 = vx * vx + vy * vy;
   }
-  const double inv_n = sqrt(n2);
-  const double theta = acos(static_cast<double>(tzf));
-  const double rx = (vx / inv_n) * theta, ry = (vy / inv_n) * theta;  // rotation vector (z component 0)
-  // scipy Rotation.from_rotvec
-  const double angle = sqrt(rx * rx + ry * ry);
-  double scale;
-  if (angle <= 1.0e-3) {
-    const double a2 = angle * angle;
-    scale = 0.5 - a2 / 48.0 + a2 * a2 / 3840.0;
-  } else {
-    scale = sin(angle / 2.0) / angle;
-  }
-  double qx = scale * rx, qy = scale * ry, qz = 0.0, qw = cos(angle / 2.0);
+  // scipy builds the unit quaternion (axis * sin(theta/2), cos(theta/2)) from the rotation vector
+  // axis * theta with theta = acos(z).  Since cos(theta) = z by definition, the half-angle identities
+  // give the same quaternion without inverse trigonometry: sin(theta/2) = sqrt((1-z)/2),
+  // cos(theta/2) = sqrt((1+z)/2); 1 -/+ z are exact in float64 for a float32 z.
+  const double norm_v = sqrt(n2);
+  const double z = static_cast<double>(tzf);
+  const double sh = sqrt(0.5 * (1.0 - z)), ch = sqrt(0.5 * (1.0 + z));
+  double qx = (vx / norm_v) * sh, qy = (vy / norm_v) * sh, qz = 0.0, qw = ch;
   const double qn = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
   qx /= qn;
   qy /= qn;

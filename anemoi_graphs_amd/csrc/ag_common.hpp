@@ -86,6 +86,8 @@ struct AgGrid {
   double inv_dlat;    // nb / pi
   const int* ncols;   // [nb]    cells in band b           (device)
   const int* off;     // [nb+1]  first cell id of band b   (device); off[nb] = number of cells
+  const double* win;  // [nb]    longitude half-width that covers the angular radius 0.98*dlat around
+                      //         any point of band b; negative = all longitudes   (device)
 };
 
 #ifdef __HIPCC__
@@ -121,6 +123,46 @@ __device__ __forceinline__ double ag_rdist(double lat1, double lon1, double lat2
 
 __device__ __forceinline__ double ag_rdist_to_dist(double r) { return 2.0 * asin(sqrt(r)); }
 
+// numpy's SIMD float32 sin/cos restated (Cody-Waite reduction by pi/2 in three float32 pieces,
+// degree-9 / degree-8 polynomials, fused multiply-adds, same constants and operation order): the
+// results are bit-identical to np.sin / np.cos of float32 arrays on FMA-capable x86, maximum error
+// 1.49 ulp.  Valid for |x| < 71476, far beyond any latitude / longitude.
+__device__ __forceinline__ void ag_np_sincos_f32(float x, float* s_out, float* c_out) {
+  const float two_over_pi = 0x1.45f306p-1f;
+  const float magic = 0x1.8p+23f;
+  float q = x * two_over_pi;
+  q = (q + magic) - magic;  // round to nearest integer
+  float r = __fmaf_rn(q, -0x1.921fb0p+00f, x);
+  r = __fmaf_rn(q, -0x1.5110b4p-22f, r);
+  r = __fmaf_rn(q, -0x1.846988p-48f, r);
+  const float r2 = r * r;
+  float sp = __fmaf_rn(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
+  sp = __fmaf_rn(sp, r2, 0x1.11119ap-07f);
+  sp = __fmaf_rn(sp, r2, -0x1.555556p-03f);
+  sp = __fmaf_rn(sp, r2, 0.0f);
+  sp = __fmaf_rn(sp, r, r);
+  float cp = __fmaf_rn(0x1.98e616p-16f, r2, -0x1.6c06dcp-10f);
+  cp = __fmaf_rn(cp, r2, 0x1.55553cp-05f);
+  cp = __fmaf_rn(cp, r2, -0x1.000000p-01f);
+  cp = __fmaf_rn(cp, r2, 1.0f);
+  const int iq = static_cast<int>(rintf(q));
+  float s = (iq & 1) ? cp : sp;
+  if (iq & 2) s = 0.0f - s;
+  const int ic = iq + 1;
+  float c = (ic & 1) ? cp : sp;
+  if (ic & 2) c = 0.0f - c;
+  *s_out = s;
+  *c_out = c;
+}
+
+// float32 unit vector computed entirely in float32 (coordinate error <= 2.1e-7)
+__device__ __forceinline__ float3 ag_unit_vec_f32(float lat, float lon) {
+  float sl, cl, so, co;
+  ag_np_sincos_f32(lat, &sl, &cl);
+  ag_np_sincos_f32(lon, &so, &co);
+  return make_float3(cl * co, cl * so, sl);
+}
+
 // float32 unit vector of a (lat, lon) point, rounded from float64
 __device__ __forceinline__ float3 ag_unit_vec(float lat, float lon) {
   double sl, cl, so, co;
@@ -129,9 +171,10 @@ __device__ __forceinline__ float3 ag_unit_vec(float lat, float lon) {
   return make_float3(static_cast<float>(cl * co), static_cast<float>(cl * so), static_cast<float>(sl));
 }
 
-// Upper bound of |fp32 chord^2 - true chord^2| for two float32 unit vectors built by ag_unit_vec
-// (coordinate error <= 2^-24 each, one rounding per subtraction / multiply / add).
-__device__ __forceinline__ float ag_chord2_err(float c2) { return 6.0e-7f * sqrtf(c2) + 4.0e-7f * c2 + 2.0e-13f; }
+// Upper bound of |fp32 chord^2 - true chord^2| when one unit vector comes from ag_unit_vec
+// (coordinate error <= 3e-8) and the other from ag_unit_vec_f32 (<= 2.1e-7): per-coordinate
+// difference error e <= 2.4e-7 + 6e-8 |d|, so |err| <= 2 sqrt(3) e sqrt(c2) + 3 e^2 + roundings.
+__device__ __forceinline__ float ag_chord2_err(float c2) { return 1.0e-6f * sqrtf(c2) + 6.0e-7f * c2 + 4.0e-13f; }
 
 // Enumerate the runs of binned points that can hold a point within angular distance R of any
 // target in the box lat in [lat_lo, lat_hi], wrapped longitude in [lon_lo, lon_hi] (lon_lo <=
@@ -194,8 +237,8 @@ struct AgBinned {
   AgGrid grid;
   int64_t n = 0;
   int64_t ncells_ub = 0;        // host-side upper bound of the number of cells
-  const float4* pts = nullptr;  // [n]  (x, y, z, bits of original id) in binned order
-  const uint64_t* keys = nullptr;  // [n] (cell << 32 | original id), sorted
+  const float4* pts = nullptr;  // [n]  (x, y, z, bits of original id) in binned order (optional)
+  const int* ids = nullptr;     // [n]  original id of every binned position
   const int* cell_start = nullptr; // [ncells_ub + 1]
 };
 
@@ -211,6 +254,10 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
 size_t ag_sort_u64_temp_bytes(int64_t n);
 int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t* d_out, int64_t n, int begin_bit,
                 int end_bit, hipStream_t stream);
+size_t ag_scan_i32_temp_bytes(int64_t n);
+// exclusive prefix sum of n int32 values, in place allowed
+int ag_exclusive_scan_i32(void* d_temp, size_t temp_bytes, const int* d_in, int* d_out, int64_t n, hipStream_t stream);
+int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream);
 size_t ag_scan_i64_temp_bytes(int64_t n);
 // exclusive prefix sum of n int64 counts into d_out[0..n] (n+1 entries; d_out[n] = total); in-place allowed
 int ag_exclusive_scan_i64(void* d_temp, size_t temp_bytes, const int64_t* d_in, int64_t* d_out, int64_t n,

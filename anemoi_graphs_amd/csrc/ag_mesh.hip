@@ -25,10 +25,6 @@ __constant__ int ag_ico_faces[20][3] = {{0, 11, 5}, {0, 5, 1},  {0, 1, 7},   {0,
                                         {3, 9, 4},  {3, 4, 2},  {3, 2, 6},   {3, 6, 8},  {3, 8, 9},
                                         {4, 9, 5},  {2, 4, 11}, {6, 2, 10},  {8, 6, 7},  {9, 8, 1}};
 
-__global__ void ag_zero_i32_kernel(int* __restrict__ p, int64_t n) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = 0;
-}
-
 static inline int64_t ag_ico_V(int l) { return 10 * (int64_t(1) << (2 * l)) + 2; }
 static inline int64_t ag_ico_F(int l) { return 20 * (int64_t(1) << (2 * l)); }
 static inline int64_t ag_ico_E(int l) { return 30 * (int64_t(1) << (2 * l)); }
@@ -241,8 +237,7 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   // ping-pong between the caller's face buffer and the workspace so that level R lands in d_faces
   int32_t* cur = (R % 2 == 0) ? d_faces : w.faces_a;
   int32_t* nxt = (R % 2 == 0) ? w.faces_a : d_faces;
-  AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(1), dim3(64), s, w.error_flag, int64_t(1));
-  AG_LAUNCH_CHECK();
+  { int rcz = ag_zero_i32(w.error_flag, 1, s); if (rcz) return rcz; }
   AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, d_xyz, cur);
   AG_LAUNCH_CHECK();
   for (int l = 0; l < R; ++l) {
@@ -448,8 +443,7 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
 
   int32_t* cur = m.topo.faces_a;
   int32_t* nxt = m.topo.faces_b;
-  AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(1), dim3(64), s, m.topo.error_flag, int64_t(1));
-  AG_LAUNCH_CHECK();
+  { int rcz = ag_zero_i32(m.topo.error_flag, 1, s); if (rcz) return rcz; }
   AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, static_cast<double*>(nullptr), cur);
   AG_LAUNCH_CHECK();
   int max_level = 0;
@@ -462,8 +456,7 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
     bool wanted = false;
     for (int i = 0; i < nlevels; ++i) wanted = wanted || (levels[i] == l);
     if (wanted) {
-      AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(ag_blocks(V, 256, 4096)), dim3(256), s, m.deg, V);
-      AG_LAUNCH_CHECK();
+      { int rcz = ag_zero_i32(m.deg, V, s); if (rcz) return rcz; }
       AG_KERNEL("ag_ms_adjacency_kernel", ag_ms_adjacency_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, m.topo.uniq, Eu, d_active, m.deg, m.adj);
       AG_LAUNCH_CHECK();
       uint64_t* pairs = m.pairs_a + slot_base;

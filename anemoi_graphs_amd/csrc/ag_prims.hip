@@ -129,6 +129,33 @@ int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t*
   return AG_OK;
 }
 
+size_t ag_scan_i32_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  int* p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, bytes, p, p, 0, static_cast<size_t>(n > 0 ? n : 1), rocprim::plus<int>(),
+                                hipStream_t(0));
+  return bytes + 256;
+}
+
+int ag_exclusive_scan_i32(void* d_temp, size_t temp_bytes, const int* d_in, int* d_out, int64_t n, hipStream_t stream) {
+  if (n <= 0) return AG_OK;
+  AgProfScope prof("rocprim_exclusive_scan", stream);
+  AG_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, d_in, d_out, 0, static_cast<size_t>(n), rocprim::plus<int>(),
+                                 stream));
+  return AG_OK;
+}
+
+__global__ void ag_zero_i32_kernel(int* __restrict__ p, int64_t n) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = 0;
+}
+
+int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream) {
+  if (n <= 0) return AG_OK;
+  AG_KERNEL("ag_zero_i32_kernel", ag_zero_i32_kernel, dim3(ag_blocks(n, 1024, 4096)), dim3(256), stream, d_ptr, n);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
 size_t ag_scan_i64_temp_bytes(int64_t n) {
   size_t bytes = 0;
   int64_t* p = nullptr;
@@ -145,6 +172,7 @@ int ag_exclusive_scan_i64(void* d_temp, size_t temp_bytes, const int64_t* d_in, 
   int64_t* in = const_cast<int64_t*>(d_in);
   AG_KERNEL("ag_zero_i64_kernel", ag_zero_i64_kernel, dim3(1), dim3(1), stream, in + n);
   AG_LAUNCH_CHECK();
+  AgProfScope prof("rocprim_exclusive_scan", stream);
   AG_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_out, int64_t(0), static_cast<size_t>(n + 1),
                                  rocprim::plus<int64_t>(), stream));
   return AG_OK;

@@ -2,42 +2,57 @@
 // radius (cut-off) queries for gfx950.
 //
 // Design
-//  * Points are binned into the latitude-band grid of ag_common.hpp by a stable radix sort of
-//    (cell << 32 | id) keys, so the binned order -- and with it every result -- is deterministic.
+//  * Points are binned into the latitude-band grid of ag_common.hpp by a counting sort: one pass
+//    takes a slot in the point's cell (atomic counter), a prefix sum turns the counts into cell
+//    starts, one pass scatters (unit vector, id) records.  The order inside a cell is arbitrary;
+//    no result depends on it (ties are broken on ids, radius rows are sorted before they are
+//    written).
 //  * k-NN, stage 1 (ag_knn_cell_kernel): one wave per target cell.  The sources of the 3 bands
 //    around the cell are staged once into an LDS tile as float32 unit vectors; every lane owns
-//    one target of the cell and scans the tile (broadcast LDS reads) keeping a sorted
-//    register list of its CAP best float32 chord^2 values.  A target is final when (a) its
-//    k-th chord provably lies inside the region the tile covers and (b) the float32 gaps around
-//    the k-th entry exceed the float32 error bound; the others are queued.
-//  * k-NN, stage 2 (ag_knn_exact_kernel): one wave per queued target, float64 haversine rdist
-//    (scikit-learn's formula) over a window that doubles until it provably holds the k nearest;
-//    the k smallest (rdist, id) pairs are extracted by k wavefront min-reductions.
+//    one target of the cell and scans the tile (broadcast LDS reads) keeping a sorted register
+//    list of its CAP >= k+2 best float32 chord^2 values.  If the float32 gaps around the k-th entry
+//    exceed the float32 error bound the list is final; otherwise the lane re-ranks the entries
+//    up to the end of the ambiguous cluster with scikit-learn's float64 haversine formula.  Only
+//    targets whose k-th chord is not provably inside the tile's coverage, or whose ambiguous
+//    cluster runs past the list, are queued for stage 2.
+//  * k-NN, stage 2 (ag_knn_exact_kernel): one wave per queued target, float64 rdist over a window
+//    that doubles until it provably holds the k nearest; the k smallest (rdist, id) pairs are
+//    extracted by k wavefront min-reductions.
 //  * Radius query: one wave per target; lanes stride over the contiguous runs of binned sources
 //    of the covering cells (coalesced 16-byte loads), float32 chord test with a float64
-//    fallback inside the error band, ballot-compacted writes.
+//    fallback inside the error band, ballot-compacted rows, sorted by source id in LDS.
 #include "ag_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // grid construction
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat, int* __restrict__ ncols,
-                                                             int* __restrict__ off) {
+                                                             int* __restrict__ off, double* __restrict__ win) {
   __shared__ int partial[1024];
   const int tid = threadIdx.x;
   const int per = (nb + 1023) / 1024;
   const int b_begin = tid * per, b_end = min(nb, b_begin + per);
+  const double rg = 0.98 * dlat;
+  const double pad = 1.0e-7 + 1.0e-6 * rg;
   int sum = 0;
   for (int b = b_begin; b < b_end; ++b) {
+    const double lat_hi = AG_HALF_PI - b * dlat, lat_lo = lat_hi - dlat;
     const double mid = AG_HALF_PI - (b + 0.5) * dlat;
     int nc = static_cast<int>(floor(AG_TWO_PI * cos(mid) / dlat));
     nc = max(nc, 1);
     ncols[b] = nc;
     sum += nc;
+    // longitude half-width of a cap of radius rg centred anywhere in the band (see ag_for_each_range)
+    const double phit = fmax(fabs(lat_lo), fabs(lat_hi));
+    double w = -1.0;
+    if (phit + rg + pad < AG_HALF_PI && rg < AG_HALF_PI) {
+      const double q = sin(rg) / cos(phit);
+      if (q < 1.0) w = asin(q) * (1.0 + 1.0e-6) + pad;
+    }
+    win[b] = w;
   }
   partial[tid] = sum;
   __syncthreads();
-  // exclusive scan of the 1024 partial sums (Hillis-Steele)
   for (int d = 1; d < 1024; d <<= 1) {
     int v = (tid >= d) ? partial[tid - d] : 0;
     __syncthreads();
@@ -52,35 +67,41 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
   if (tid == 1023) off[nb] = partial[1023];
 }
 
-__global__ void ag_cell_key_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n, uint64_t* __restrict__ keys) {
+__global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n, int* __restrict__ cell_of,
+                                    int* __restrict__ slot_of, int* __restrict__ count) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     const float2 p = pts[i];
     const int c = ag_cell_of(g, static_cast<double>(p.x), static_cast<double>(p.y));
-    keys[i] = (static_cast<uint64_t>(c) << 32) | static_cast<uint32_t>(i);
-  }
-}
-
-// cell_start[c] = first binned position whose cell id is >= c  (c in [0, ncells_ub])
-__global__ void ag_cell_start_kernel(const uint64_t* __restrict__ keys, int64_t n, int64_t ncells_ub,
-                                     int* __restrict__ cell_start) {
-  for (int64_t c = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; c <= ncells_ub; c += int64_t(gridDim.x) * blockDim.x) {
-    const uint64_t want = static_cast<uint64_t>(c) << 32;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    cell_of[i] = c;
+    // neighbouring points usually share a cell: one atomic per distinct cell of the wave
+    const int lane = ag_lane();
+    unsigned long long todo = __ballot(1);
+    int slot = 0;
+    while (todo) {
+      const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+      const int c0 = __shfl(c, leader, 64);
+      const unsigned long long same = __ballot(c == c0) & todo;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&count[c0], __popcll(same));
+      base = __shfl(base, leader, 64);
+      if (c == c0) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+      todo &= ~same;
     }
-    cell_start[c] = static_cast<int>(lo);
+    slot_of[i] = slot;
   }
 }
 
-__global__ void ag_binned_points_kernel(const uint64_t* __restrict__ keys, const float2* __restrict__ pts, int64_t n,
-                                        float4* __restrict__ out) {
+__global__ void ag_bin_scatter_kernel(const float2* __restrict__ pts, int64_t n, const int* __restrict__ cell_of,
+                                      const int* __restrict__ slot_of, const int* __restrict__ cell_start,
+                                      float4* __restrict__ out_pts, int* __restrict__ out_ids) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint32_t id = static_cast<uint32_t>(keys[i]);
-    const float2 p = pts[id];
-    const float3 u = ag_unit_vec(p.x, p.y);
-    out[i] = make_float4(u.x, u.y, u.z, __int_as_float(static_cast<int>(id)));
+    const int pos = cell_start[cell_of[i]] + slot_of[i];
+    out_ids[pos] = static_cast<int>(i);
+    if (out_pts != nullptr) {
+      const float2 p = pts[i];
+      const float3 u = ag_unit_vec(p.x, p.y);
+      out_pts[pos] = make_float4(u.x, u.y, u.z, __int_as_float(static_cast<int>(i)));
+    }
   }
 }
 
@@ -97,47 +118,64 @@ static int64_t ag_grid_cells_ub(int nb) {
   return static_cast<int64_t>(4.0 * AG_PI / (dlat * dlat) * 1.02) + nb + 64;
 }
 
+struct AgBinCarve {
+  int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids;
+  double* win;
+  float4* pts;
+  void* scan_temp;
+  size_t scan_temp_bytes;
+};
+
+static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, bool want_pts, AgBinCarve* c) {
+  const int64_t cells = ag_grid_cells_ub(nb_reserve) + 1;
+  c->ncols = ws.take<int>(nb_reserve);
+  c->off = ws.take<int>(nb_reserve + 1);
+  c->win = ws.take<double>(nb_reserve);
+  c->cell_start = ws.take<int>(cells);
+  c->cell_of = ws.take<int>(n);
+  c->slot_of = ws.take<int>(n);
+  c->ids = ws.take<int>(n);
+  c->scan_temp_bytes = ag_scan_i32_temp_bytes(cells);
+  c->scan_temp = ws.take<char>(c->scan_temp_bytes);
+  c->pts = want_pts ? ws.take<float4>(n) : nullptr;
+}
+
+static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, AgBinned* out) {
+  out->grid.nb = nb;
+  out->grid.dlat = AG_PI / nb;
+  out->grid.inv_dlat = nb / AG_PI;
+  out->grid.ncols = c.ncols;
+  out->grid.off = c.off;
+  out->grid.win = c.win;
+  out->n = n;
+  out->ncells_ub = ag_grid_cells_ub(nb);
+  out->pts = c.pts;
+  out->ids = c.ids;
+  out->cell_start = c.cell_start;
+}
+
 int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, bool want_pts,
                   hipStream_t stream, AgBinned* out) {
   if (nb_reserve < nb) nb_reserve = nb;
-  const int64_t ncells_ub = ag_grid_cells_ub(nb);
-  int* ncols = ws.take<int>(nb_reserve);
-  int* off = ws.take<int>(nb_reserve + 1);
-  int* cell_start = ws.take<int>(ag_grid_cells_ub(nb_reserve) + 1);
-  uint64_t* keys_a = ws.take<uint64_t>(n);
-  uint64_t* keys_b = ws.take<uint64_t>(n);
-  const size_t temp_bytes = ag_sort_u64_temp_bytes(n);
-  void* temp = ws.take<char>(temp_bytes);
-  float4* pts = want_pts ? ws.take<float4>(n) : nullptr;
+  AgBinCarve c;
+  ag_bin_carve(ws, n, nb_reserve, want_pts, &c);
   if (out == nullptr) return AG_OK;  // sizing pass
-
-  AgGrid g;
-  g.nb = nb;
-  g.dlat = AG_PI / nb;
-  g.inv_dlat = nb / AG_PI;
-  g.ncols = ncols;
-  g.off = off;
-  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(1), dim3(1024), stream, nb, g.dlat, ncols, off);
+  ag_bin_describe(c, n, nb, out);
+  const int64_t ncells_ub = out->ncells_ub;
+  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(1), dim3(1024), stream, nb, out->grid.dlat, c.ncols,
+            c.off, c.win);
   AG_LAUNCH_CHECK();
-  const int blocks = ag_blocks(n, 256, 16384);
-  AG_KERNEL("ag_cell_key_kernel", ag_cell_key_kernel, dim3(blocks), dim3(256), stream, g, reinterpret_cast<const float2*>(d_pts), n, keys_a);
-  AG_LAUNCH_CHECK();
-  int cell_bits = 1;
-  while ((int64_t(1) << cell_bits) <= ncells_ub) ++cell_bits;
-  int rc = ag_sort_u64(temp, temp_bytes, keys_a, keys_b, n, 32, 32 + cell_bits, stream);
+  int rc = ag_zero_i32(c.cell_start, ncells_ub + 1, stream);
   if (rc) return rc;
-  AG_KERNEL("ag_cell_start_kernel", ag_cell_start_kernel, dim3(ag_blocks(ncells_ub + 1, 256, 16384)), dim3(256), stream, keys_b, n, ncells_ub, cell_start);
+  const int blocks = ag_blocks(n, 256, 16384);
+  AG_KERNEL("ag_bin_count_kernel", ag_bin_count_kernel, dim3(blocks), dim3(256), stream, out->grid,
+            reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start);
   AG_LAUNCH_CHECK();
-  if (want_pts) {
-    AG_KERNEL("ag_binned_points_kernel", ag_binned_points_kernel, dim3(blocks), dim3(256), stream, keys_b, reinterpret_cast<const float2*>(d_pts), n, pts);
-    AG_LAUNCH_CHECK();
-  }
-  out->grid = g;
-  out->n = n;
-  out->ncells_ub = ncells_ub;
-  out->pts = pts;
-  out->keys = keys_b;
-  out->cell_start = cell_start;
+  rc = ag_exclusive_scan_i32(c.scan_temp, c.scan_temp_bytes, c.cell_start, c.cell_start, ncells_ub + 1, stream);
+  if (rc) return rc;
+  AG_KERNEL("ag_bin_scatter_kernel", ag_bin_scatter_kernel, dim3(blocks), dim3(256), stream,
+            reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start, c.pts, c.ids);
+  AG_LAUNCH_CHECK();
   return AG_OK;
 }
 
@@ -151,7 +189,7 @@ struct AgKnnArgs {
   AgGrid grid;
   const float4* spts;        // binned sources
   const int* sstart;         // source cell starts
-  const uint64_t* tkeys;     // binned target keys (cell << 32 | id)
+  const int* tids;           // binned target ids
   const int* tstart;         // target cell starts (same grid)
   const float2* tgt;         // target coordinates, original order
   const float2* src;         // source coordinates, original order
@@ -164,7 +202,8 @@ struct AgKnnArgs {
   int* queue;                // [nt] targets left to stage 2
   int* queue_count;
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
-  unsigned long long* max_bits;  // reference-distance mode: running max of rdist (as uint64 bits)
+  unsigned long long* max_bits;  // reference-distance mode: running max of rdist of stage 2 (uint64 bits)
+  double* cell_max;          // reference-distance mode: per-cell max of rdist of stage 1 [ncells_ub]
   long long* stats;          // [4]
 };
 
@@ -186,6 +225,53 @@ __device__ __forceinline__ void ag_topk_insert(float (&bd)[CAP], int (&bi)[CAP],
   }
 }
 
+__device__ __forceinline__ bool ag_pair_less(double r1, int i1, double r2, int i2) {
+  return (r1 < r2) || (r1 == r2 && i1 < i2);
+}
+
+__device__ __forceinline__ double ag_wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Enumerates, for the target cell (band, col), the runs of binned sources within the guaranteed
+// radius of any point of the cell, using the per-band longitude half-width table.
+template <class F>
+__device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __restrict__ cell_start, int band, int col,
+                                               F&& f) {
+  const int nc = g.ncols[band];
+  const double wlon = AG_TWO_PI / nc;
+  const double delta = g.win[band];
+  const bool full = delta < 0.0;
+  const double lo = col * wlon - delta, hi = (col + 1) * wlon + delta;
+  const int b0 = max(band - 1, 0), b1 = min(band + 1, g.nb - 1);
+  for (int b = b0; b <= b1; ++b) {
+    const int ncb = g.ncols[b];
+    const int base = g.off[b];
+    if (full || ncb == 1 || hi - lo >= AG_TWO_PI) {
+      f(cell_start[base], cell_start[base + ncb]);
+      continue;
+    }
+    const double w = ncb * AG_INV_TWO_PI;
+    const long long ca = static_cast<long long>(floor(lo * w));
+    const long long cb = static_cast<long long>(floor(hi * w));
+    const long long len = cb - ca + 1;
+    if (len >= ncb) {
+      f(cell_start[base], cell_start[base + ncb]);
+      continue;
+    }
+    int cam = static_cast<int>(ca % ncb);
+    if (cam < 0) cam += ncb;
+    if (cam + len <= ncb) {
+      f(cell_start[base + cam], cell_start[base + cam + static_cast<int>(len)]);
+    } else {
+      f(cell_start[base + cam], cell_start[base + ncb]);
+      f(cell_start[base], cell_start[base + cam + static_cast<int>(len) - ncb]);
+    }
+  }
+}
+
 template <int CAP>
 __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(AgKnnArgs a) {
   __shared__ float4 tile_all[AG_WAVES_PER_BLOCK][AG_TILE];
@@ -196,21 +282,16 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
   const int cell = __builtin_amdgcn_readfirstlane(blockIdx.x * AG_WAVES_PER_BLOCK + wave);
   if (cell >= ncells) return;
   const int t0 = a.tstart[cell], t1 = a.tstart[cell + 1];
-  if (t0 >= t1) return;
-
-  // band and column of this cell (binary search in the band offsets)
-  int blo = 0, bhi = a.grid.nb - 1;
-  while (blo < bhi) {
-    const int mid = (blo + bhi + 1) >> 1;
-    if (a.grid.off[mid] <= cell) blo = mid; else bhi = mid - 1;
+  if (t0 >= t1) {
+    if (a.self_query && lane == 0) a.cell_max[cell] = 0.0;
+    return;
   }
-  const int band = blo;
+  double cell_max = 0.0;
+
+  // band of this cell from its first target (every target of a cell shares the band)
+  const float2 first = a.tgt[a.tids[t0]];
+  const int band = __builtin_amdgcn_readfirstlane(ag_band_of(a.grid, static_cast<double>(first.x)));
   const int col = cell - a.grid.off[band];
-  const int nc = a.grid.ncols[band];
-  const double lat_hi = AG_HALF_PI - band * a.grid.dlat;
-  const double lat_lo = lat_hi - a.grid.dlat;
-  const double wlon = AG_TWO_PI / nc;
-  const double lon_lo = col * wlon, lon_hi = (col + 1) * wlon;
   const int k = a.k;
 
   for (int tb = t0; tb < t1; tb += 64) {
@@ -220,9 +301,9 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     float3 tu = make_float3(0.f, 0.f, 0.f);
     float2 tp = make_float2(0.f, 0.f);
     if (active) {
-      tid = static_cast<int>(static_cast<uint32_t>(a.tkeys[ti]));
+      tid = a.tids[ti];
       tp = a.tgt[tid];
-      tu = ag_unit_vec(tp.x, tp.y);
+      tu = ag_unit_vec_f32(tp.x, tp.y);
     }
     float bd[CAP];
     int bi[CAP];
@@ -245,10 +326,10 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     };
-    ag_for_each_range(a.grid, a.sstart, lat_lo, lat_hi, lon_lo, lon_hi, a.rg, [&](int first, int last) {
-      int pos = first;
-      while (pos < last) {
-        const int take = min(last - pos, AG_TILE - fill);
+    ag_cell_window(a.grid, a.sstart, band, col, [&](int first_pos, int last_pos) {
+      int pos = first_pos;
+      while (pos < last_pos) {
+        const int take = min(last_pos - pos, AG_TILE - fill);
         for (int i = lane; i < take; i += 64) tile[fill + i] = a.spts[pos + i];
         fill += take;
         pos += take;
@@ -260,60 +341,106 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     });
     if (fill > 0) scan_tile(fill);
 
-    if (!active) continue;
-    // (a) coverage: the k-th chord must lie inside the guaranteed radius;
-    // (b) the float32 order around the k-th entry must be beyond the rounding error
+    // ---- classify -------------------------------------------------------------------------
+    // Let dk be the float32 chord^2 of the k-th entry and ek its error bound.  Every candidate whose
+    // float32 value exceeds thr_hi = dk + 3 ek + 4e-12 is provably farther (in exact arithmetic)
+    // than each of the first k entries [x - err(x) >= dk + ek for x >= thr_hi], so the exact k nearest
+    // are among the entries up to the last one below thr_hi ("cluster end" c1).  The list is
+    //   final      if c1 is the k-th entry itself and the first k gaps exceed their error bounds,
+    //   re-ranked  in float64 (scikit-learn's formula, ties on ids) if c1 lies inside the list,
+    //   queued     if the cluster may run past the list or the k-th entry is not provably inside
+    //              the region the tile covers.
+    constexpr bool RESOLVE = (CAP <= 12);
     const float dk = bd[k - 1];
-    bool settled = (bi[k - 1] >= 0) && (dk + ag_chord2_err(dk) <= a.rg_chord2);
-    if (settled) {
-      const float dn = bd[k];  // CAP >= k + 1
-      settled = (dn - dk) > (ag_chord2_err(dn) + ag_chord2_err(dk));
-    }
-    bool order_ok = true;
-    if (settled) {
+    const float ek = ag_chord2_err(dk);
+    const float thr_hi = dk + 3.0f * ek + 4.0e-12f;
+    const bool have_k = active && (bi[k - 1] >= 0);
+    bool queued = active && !have_k;
+    int c1 = k - 1;
+#pragma unroll
+    for (int j = 0; j < CAP; ++j)
+      if (j >= k && bd[j] <= thr_hi) c1 = j;
+    bool exact = false;
+    if (have_k) {
+      if (c1 == CAP - 1) queued = true;
+      if (dk + ek > a.rg_chord2) queued = true;
+      exact = (c1 != k - 1);
 #pragma unroll
       for (int j = 0; j + 1 < CAP; ++j)
-        if (j + 1 < k) order_ok = order_ok && ((bd[j + 1] - bd[j]) > (ag_chord2_err(bd[j + 1]) + ag_chord2_err(bd[j])));
+        if (j + 1 < k) exact = exact || ((bd[j + 1] - bd[j]) <= (ag_chord2_err(bd[j + 1]) + ag_chord2_err(bd[j])));
+      if (a.self_query) exact = true;  // the value of the 2nd smallest rdist is needed anyway
+      if (!RESOLVE && exact) queued = true;
     }
-    if (a.self_query) {
-      // reference distance: the 2nd smallest float64 rdist of this point's neighbourhood
-      if (settled) {
-        double r0 = 0.0, r1 = 0.0;
-        {
-          const float2 p = a.src[bi[0]];
-          r0 = ag_rdist(tp.x, tp.y, p.x, p.y);
-        }
-        {
-          const float2 p = a.src[bi[1]];
-          r1 = ag_rdist(tp.x, tp.y, p.x, p.y);
-        }
-        const double r = fmax(r0, r1);
-        if (r > 0.0) atomicMax(a.max_bits, static_cast<unsigned long long>(__double_as_longlong(r)));
-      } else {
-        const int slot = atomicAdd(a.queue_count, 1);
-        a.queue[slot] = tid;
-      }
-      continue;
-    }
-    if (settled && order_ok) {
-      int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
+    const bool done = have_k && !queued;
+
+    if constexpr (RESOLVE) {
+      double rr[CAP];  // float64 rdist of the entries (only where needed)
 #pragma unroll
-      for (int j = 0; j < CAP; ++j)
-        if (j < k) o[j] = bi[j];
-      if (a.out_dist != nullptr) {
-        double* od = a.out_dist + static_cast<int64_t>(tid) * k;
+      for (int j = 0; j < CAP; ++j) rr[j] = 1.0e300;
+      if (done && (exact || a.out_dist != nullptr)) {
+        const int upto = exact ? c1 : k - 1;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) {
+          if (j <= upto) {
+            const float2 p = a.src[bi[j]];
+            rr[j] = ag_rdist(tp.x, tp.y, p.x, p.y);
+          }
+        }
+      }
+      if (done && exact) {
+        // selection sort of the (rdist, id) pairs, fully unrolled so everything stays in registers
+#pragma unroll
+        for (int i = 0; i < CAP - 1; ++i) {
+#pragma unroll
+          for (int j = i + 1; j < CAP; ++j) {
+            const bool sw = ag_pair_less(rr[j], bi[j], rr[i], bi[i]);
+            const double r0 = sw ? rr[j] : rr[i], r1 = sw ? rr[i] : rr[j];
+            const int i0 = sw ? bi[j] : bi[i], i1 = sw ? bi[i] : bi[j];
+            rr[i] = r0;
+            rr[j] = r1;
+            bi[i] = i0;
+            bi[j] = i1;
+          }
+        }
+      }
+      if (a.self_query) {
+        const double r = done ? rr[1] : 0.0;
+        cell_max = fmax(cell_max, ag_wave_max_f64(r));
+      } else if (done) {
+        int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
 #pragma unroll
         for (int j = 0; j < CAP; ++j)
-          if (j < k) {
-            const float2 p = a.src[bi[j]];
-            od[j] = ag_rdist_to_dist(ag_rdist(tp.x, tp.y, p.x, p.y));
-          }
+          if (j < k) o[j] = bi[j];
+        if (a.out_dist != nullptr) {
+          double* od = a.out_dist + static_cast<int64_t>(tid) * k;
+#pragma unroll
+          for (int j = 0; j < CAP; ++j)
+            if (j < k) od[j] = ag_rdist_to_dist(rr[j]);
+        }
       }
     } else {
+      if (done) {
+        int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j)
+          if (j < k) o[j] = bi[j];
+        if (a.out_dist != nullptr) {
+          double* od = a.out_dist + static_cast<int64_t>(tid) * k;
+#pragma unroll
+          for (int j = 0; j < CAP; ++j)
+            if (j < k) {
+              const float2 p = a.src[bi[j]];
+              od[j] = ag_rdist_to_dist(ag_rdist(tp.x, tp.y, p.x, p.y));
+            }
+        }
+      }
+    }
+    if (queued) {
       const int slot = atomicAdd(a.queue_count, 1);
       a.queue[slot] = tid;
     }
   }
+  if (a.self_query && lane == 0) a.cell_max[cell] = cell_max;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,10 +450,6 @@ struct AgPair {
   double r;
   int id;
 };
-
-__device__ __forceinline__ bool ag_pair_less(double r1, int i1, double r2, int i2) {
-  return (r1 < r2) || (r1 == r2 && i1 < i2);
-}
 
 __device__ __forceinline__ AgPair ag_wave_min_pair(double r, int id) {
 #pragma unroll
@@ -361,7 +484,6 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       const double rlimit = s * s * (1.0 - 1.0e-9);
       double prev_r = -1.0;
       int prev_i = -1;
-      int found = 0;
       bool covered = true;
       for (int j = 0; j < k; ++j) {
         double best_r = 1.0e300;
@@ -388,7 +510,6 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
         }
         prev_r = m.r;
         prev_i = m.id;
-        ++found;
         if (a.self_query) {
           if (j == 1 && lane == 0 && m.r > 0.0)
             atomicMax(a.max_bits, static_cast<unsigned long long>(__double_as_longlong(m.r)));
@@ -418,9 +539,20 @@ __global__ void ag_knn_init_kernel(int* queue_count, unsigned long long* max_bit
   }
 }
 
-__global__ void ag_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
-  const double r = __longlong_as_double(static_cast<long long>(*max_bits));
-  *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
+__global__ __launch_bounds__(1024) void ag_maxdist_finish_kernel(AgGrid g, const double* __restrict__ cell_max,
+                                                                 const unsigned long long* max_bits, double* out) {
+  __shared__ double sh[16];
+  const int ncells = g.off[g.nb];
+  double r = 0.0;
+  for (int c = threadIdx.x; c < ncells; c += blockDim.x) r = fmax(r, cell_max[c]);
+  r = ag_wave_max_f64(r);
+  if (ag_lane() == 0) sh[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) r = fmax(r, sh[w]);
+    r = fmax(r, __longlong_as_double(static_cast<long long>(*max_bits)));
+    *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
+  }
 }
 
 // cell size for a k-NN search over ns quasi-uniform sources: the disc of radius delta holds
@@ -437,6 +569,7 @@ struct AgKnnWs {
   int* queue;
   int* queue_count;
   unsigned long long* max_bits;
+  double* cell_max;
 };
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
@@ -453,7 +586,9 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* queue = c.take<int>(nt);
   int* queue_count = c.take<int>(4);
   unsigned long long* max_bits = c.take<unsigned long long>(2);
+  double* cell_max = self_query ? c.take<double>(ag_grid_cells_ub(nb) + 1) : nullptr;
   if (w) {
+    w->cell_max = cell_max;
     w->queue = queue;
     w->queue_count = queue_count;
     w->max_bits = max_bits;
@@ -477,14 +612,15 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   AgKnnWs w;
   int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w);
   if (rc) return rc;
-  AG_KERNEL("ag_knn_init_kernel", ag_knn_init_kernel, dim3(1), dim3(64), stream, w.queue_count, w.max_bits, reinterpret_cast<long long*>(d_stats));
+  AG_KERNEL("ag_knn_init_kernel", ag_knn_init_kernel, dim3(1), dim3(64), stream, w.queue_count, w.max_bits,
+            reinterpret_cast<long long*>(d_stats));
   AG_LAUNCH_CHECK();
 
   AgKnnArgs a;
   a.grid = w.src.grid;
   a.spts = w.src.pts;
   a.sstart = w.src.cell_start;
-  a.tkeys = w.tgt.keys;
+  a.tids = w.tgt.ids;
   a.tstart = w.tgt.cell_start;
   a.tgt = reinterpret_cast<const float2*>(d_tgt);
   a.src = reinterpret_cast<const float2*>(d_src);
@@ -502,20 +638,25 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.queue_count = w.queue_count;
   a.self_query = self_query ? 1 : 0;
   a.max_bits = w.max_bits;
+  a.cell_max = w.cell_max;
   a.stats = reinterpret_cast<long long*>(d_stats);
 
   const int64_t ncu = w.src.ncells_ub;
-  if (k + 1 <= 2) ag_launch_cell_kernel<2>(a, ncu, stream);
-  else if (k + 1 <= 4) ag_launch_cell_kernel<4>(a, ncu, stream);
-  else if (k + 1 <= 8) ag_launch_cell_kernel<8>(a, ncu, stream);
-  else if (k + 1 <= 16) ag_launch_cell_kernel<16>(a, ncu, stream);
-  else if (k + 1 <= 32) ag_launch_cell_kernel<32>(a, ncu, stream);
-  else ag_launch_cell_kernel<AG_KNN_MAX_K + 1>(a, ncu, stream);
+  // list capacity: k entries, the (k+1)-th as the boundary witness, and room for an ambiguous cluster
+  if (self_query) ag_launch_cell_kernel<8>(a, ncu, stream);
+  else if (k + 2 <= 3) ag_launch_cell_kernel<3>(a, ncu, stream);
+  else if (k + 2 <= 5) ag_launch_cell_kernel<5>(a, ncu, stream);
+  else if (k + 2 <= 8) ag_launch_cell_kernel<8>(a, ncu, stream);
+  else if (k + 2 <= 12) ag_launch_cell_kernel<12>(a, ncu, stream);
+  else if (k + 2 <= 18) ag_launch_cell_kernel<18>(a, ncu, stream);
+  else if (k + 2 <= 34) ag_launch_cell_kernel<34>(a, ncu, stream);
+  else ag_launch_cell_kernel<AG_KNN_MAX_K + 2>(a, ncu, stream);
   AG_LAUNCH_CHECK();
   AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
   AG_LAUNCH_CHECK();
   if (self_query) {
-    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1), stream, w.max_bits, d_out_max);
+    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1024), stream, w.src.grid,
+              w.cell_max, w.max_bits, d_out_max);
     AG_LAUNCH_CHECK();
   }
   return AG_OK;
@@ -559,6 +700,8 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
 // ---------------------------------------------------------------------------------------------
 // radius query
 // ---------------------------------------------------------------------------------------------
+#define AG_ROW_LDS 1024  // row entries a wave can sort in LDS
+
 struct AgRadiusArgs {
   AgGrid grid;
   const float4* spts;
@@ -576,7 +719,10 @@ struct AgRadiusArgs {
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void ag_radius_kernel(AgRadiusArgs a) {
+  __shared__ __attribute__((aligned(16))) int row_all[FILL ? 4 : 1][FILL ? AG_ROW_LDS + 4 : 4];
   const int lane = ag_lane();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int* row = row_all[FILL ? wave : 0];
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
   for (int64_t t = wave_global; t < a.nt; t += nwaves) {
@@ -586,6 +732,8 @@ __global__ __launch_bounds__(256) void ag_radius_kernel(AgRadiusArgs a) {
     const float3 tu = ag_unit_vec(tpf.x, tpf.y);
     int64_t cnt = 0;
     const int64_t base_out = FILL ? a.offsets[t] : 0;
+    const int64_t n_row = FILL ? a.offsets[t + 1] - base_out : 0;
+    const bool in_lds = FILL && n_row <= AG_ROW_LDS;
     ag_for_each_range(a.grid, a.sstart, tlat, tlat, tlonw, tlonw, a.radius, [&](int first, int last) {
       for (int p0 = first; p0 < last; p0 += 64) {
         const int p = p0 + lane;
@@ -604,14 +752,56 @@ __global__ __launch_bounds__(256) void ag_radius_kernel(AgRadiusArgs a) {
         }
         const unsigned long long m = __ballot(in);
         if (FILL && in) {
-          const int64_t o = base_out + cnt + __popcll(m & ((1ull << lane) - 1ull));
-          a.out_src[o] = id;
-          if (a.out_tgt) a.out_tgt[o] = static_cast<int32_t>(t);
+          const int64_t o = cnt + __popcll(m & ((1ull << lane) - 1ull));
+          if (in_lds) row[o] = id;
+          else a.out_tgt[base_out + o] = id;  // the target column doubles as scratch for long rows
         }
         cnt += __popcll(m);
       }
     });
-    if (!FILL && lane == 0) a.offsets[t] = cnt;
+    if (!FILL) {
+      if (lane == 0) a.offsets[t] = cnt;
+      continue;
+    }
+    // rank sort: source ids are distinct inside a row, so rank = number of smaller ids
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (in_lds) {
+      const int n = static_cast<int>(n_row);
+      const int n4 = (n + 3) & ~3;
+      if (lane < n4 - n) row[n + lane] = 0x7fffffff;  // pad to a multiple of 4 with a value that ranks last
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int4* row4 = reinterpret_cast<const int4*>(row);
+      for (int e0 = 0; e0 < n; e0 += 128) {
+        // two elements per lane share every broadcast read of four row entries
+        const int ea = e0 + lane, eb = e0 + 64 + lane;
+        const int va = ea < n ? row[ea] : 0x7fffffff, vb = eb < n ? row[eb] : 0x7fffffff;
+        int ra = 0, rb = 0;
+        for (int j = 0; j < n4 / 4; ++j) {
+          const int4 q = row4[j];
+          ra += (q.x < va) + (q.y < va) + (q.z < va) + (q.w < va);
+          rb += (q.x < vb) + (q.y < vb) + (q.z < vb) + (q.w < vb);
+        }
+        if (ea < n) a.out_src[base_out + ra] = va;
+        if (eb < n) a.out_src[base_out + rb] = vb;
+      }
+      for (int e = lane; e < n; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
+    } else {
+      for (int64_t e = lane; e < n_row; e += 64) {
+        const int mine = a.out_tgt[base_out + e];
+        int64_t rank = 0;
+        for (int64_t j = 0; j < n_row; ++j) rank += (a.out_tgt[base_out + j] < mine) ? 1 : 0;
+        a.out_src[base_out + rank] = mine;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int64_t e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -643,23 +833,9 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
     if (rc) return rc;
   } else {
     // descriptor of the grid the count pass built in this workspace (same carve, no kernels)
-    int* ncols = c.take<int>(nb_reserve);
-    int* off = c.take<int>(nb_reserve + 1);
-    int* cell_start = c.take<int>(ag_grid_cells_ub(nb_reserve) + 1);
-    (void)c.take<uint64_t>(ns);
-    uint64_t* keys_b = c.take<uint64_t>(ns);
-    (void)c.take<char>(ag_sort_u64_temp_bytes(ns));
-    float4* pts = c.take<float4>(ns);
-    w->src.grid.nb = nb;
-    w->src.grid.dlat = AG_PI / nb;
-    w->src.grid.inv_dlat = nb / AG_PI;
-    w->src.grid.ncols = ncols;
-    w->src.grid.off = off;
-    w->src.n = ns;
-    w->src.ncells_ub = ag_grid_cells_ub(nb);
-    w->src.pts = pts;
-    w->src.keys = keys_b;
-    w->src.cell_start = cell_start;
+    AgBinCarve bc;
+    ag_bin_carve(c, ns, nb_reserve, true, &bc);
+    ag_bin_describe(bc, ns, nb, &w->src);
   }
   const size_t stb = ag_scan_i64_temp_bytes(nt);
   void* st = c.take<char>(stb);
@@ -689,6 +865,7 @@ static int ag_radius_args(const float* d_src, const float* d_tgt, int64_t nt, do
   const double s = sin(0.5 * radius);
   a->rthr = s * s;
   const double c2 = 4.0 * s * s;
+  // both unit vectors are rounded from float64 here: coordinate error <= 2^-24
   const double err = 6.0e-7 * sqrt(c2) + 4.0e-7 * c2 + 2.0e-13;
   a->c_in = static_cast<float>((c2 - 2.0 * err) * (1.0 - 1.0e-6));
   a->c_out = static_cast<float>((c2 + 2.0 * err) * (1.0 + 1.0e-6));
@@ -718,7 +895,7 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
   a.out_src = nullptr;
   a.out_tgt = nullptr;
   if (nt > 0) {
-    AG_KERNEL("ag_radius_kernel", ag_radius_kernel<false>, dim3(ag_blocks(nt, 4, 8192)), dim3(256), s, a);
+    AG_KERNEL("ag_radius_kernel_count", ag_radius_kernel<false>, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
   return ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
@@ -729,7 +906,7 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
                               size_t ws_bytes, void* stream) {
   AG_REQUIRE(ns >= 1 && nt >= 0, "ag_radius_fill: bad sizes");
   if (nt == 0) return AG_OK;
-  AG_REQUIRE(d_src && d_tgt && d_offsets && d_out_src && d_ws, "ag_radius_fill: null pointer");
+  AG_REQUIRE(d_src && d_tgt && d_offsets && d_out_src && d_out_tgt && d_ws, "ag_radius_fill: null pointer");
   if (ws_bytes < ag_radius_workspace_bytes(ns, nt)) return ag_fail(AG_ERR_WORKSPACE, "ag_radius_fill: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AgCarver c(d_ws);
@@ -741,7 +918,7 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
   a.offsets = const_cast<int64_t*>(d_offsets);
   a.out_src = d_out_src;
   a.out_tgt = d_out_tgt;
-  AG_KERNEL("ag_radius_kernel", ag_radius_kernel<true>, dim3(ag_blocks(nt, 4, 8192)), dim3(256), s, a);
+  AG_KERNEL("ag_radius_kernel_fill", ag_radius_kernel<true>, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

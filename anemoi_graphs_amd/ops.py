@@ -88,8 +88,8 @@ def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, sort: bool = True) -> torch.Tensor:
-    """edge_index [2,E] int32 (row 0 source id, row 1 target id), target-major."""
+def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float) -> torch.Tensor:
+    """edge_index [2,E] int32 (row 0 source id, row 1 target id), sorted by (target, source)."""
     lib = _lib.load()
     dev = device_of(src, tgt)
     src, tgt = coords(src, dev), coords(tgt, dev)
@@ -110,8 +110,6 @@ def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, sort: bool
                                    _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_radius_fill",
             )
-            if sort:
-                sort_edges_(edge_index, by_target=True)
     return edge_index
 
 

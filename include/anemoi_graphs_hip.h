@@ -77,7 +77,8 @@ int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, 
  * exclusive prefix sum of the per-target match counts to d_offsets[0..nt] (d_offsets[nt] =
  * number of edges E); the caller reads E, allocates, and calls ag_radius_fill with the SAME
  * arguments and the SAME untouched workspace.  Rows are target-major; inside a row source
- * ids ascend.  d_out_tgt may be NULL.
+ * ids ascend (the rows are sorted in LDS before they are written).  d_out_tgt [E] is required:
+ * it receives the target id of every edge and serves as scratch for rows longer than 1024.
  */
 size_t ag_radius_workspace_bytes(int64_t ns, int64_t nt);
 int ag_radius_count(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,

@@ -27,7 +27,7 @@ def nn_maxdist(x):
     return torch.tensor(rp.grid_reference_distance(_np(x)), dtype=torch.float64)
 
 
-def radius_edges(src, tgt, radius, sort=True):
+def radius_edges(src, tgt, radius):
     e = rp.radius_edges(_np(src), _np(tgt), radius)
     return torch.from_numpy(np.ascontiguousarray(rp.canonical_sort(e)))
 

@@ -29,7 +29,6 @@ print("   knn stats (exact-path targets, extra rounds):", stats.tolist())
 timed("nn_maxdist hidden", lambda: ops.nn_maxdist(hidden))
 r = float(ops.nn_maxdist(hidden).item()) * 0.6
 enc = timed("radius enc", lambda: ops.radius_edges(data, hidden, r))
-timed("radius enc nosort", lambda: ops.radius_edges(data, hidden, r, sort=False))
 proc = timed("multiscale", lambda: ops.multiscale_edges(res, list(range(res + 1)), 1, rank))
 timed("icosphere", lambda: ops.icosphere(res, dev))
 dec = torch.stack([ids.reshape(-1), torch.arange(data.shape[0], dtype=torch.int32, device=dev).repeat_interleave(3)])
