@@ -240,6 +240,7 @@ struct AgBinned {
   const float4* pts = nullptr;  // [n]  (x, y, z, bits of original id) in binned order (optional)
   const int* ids = nullptr;     // [n]  original id of every binned position
   const int* cell_start = nullptr; // [ncells_ub + 1]
+  const int* cell_band = nullptr;  // [ncells_ub] band of every cell (grids binned without unit vectors)
 };
 
 // Number of latitude bands for cells of about `delta` radians.
@@ -247,7 +248,8 @@ int ag_grid_bands(double delta);
 // Bins n points into a grid of nb bands; carves everything it needs from `ws`, with the cell
 // tables sized for nb_reserve (>= nb) bands so that the carve can be made independent of nb.
 // out == nullptr: sizing pass only.
-int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, bool want_pts,
+// `mult` multiplies the number of longitude cells of every band (finer cells for dense target sets).
+int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, int mult, bool want_pts,
                   hipStream_t stream, AgBinned* out);
 
 // device-wide primitives (rocPRIM behind a plain interface)

@@ -26,7 +26,7 @@
 // ---------------------------------------------------------------------------------------------
 // grid construction
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat, int* __restrict__ ncols,
+__global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat, int mult, int* __restrict__ ncols,
                                                              int* __restrict__ off, double* __restrict__ win) {
   __shared__ int partial[1024];
   const int tid = threadIdx.x;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
     const double lat_hi = AG_HALF_PI - b * dlat, lat_lo = lat_hi - dlat;
     const double mid = AG_HALF_PI - (b + 0.5) * dlat;
     int nc = static_cast<int>(floor(AG_TWO_PI * cos(mid) / dlat));
-    nc = max(nc, 1);
+    nc = max(nc, 1) * mult;
     ncols[b] = nc;
     sum += nc;
     // longitude half-width of a cap of radius rg centred anywhere in the band (see ag_for_each_range)
@@ -65,6 +65,19 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
     run += ncols[b];
   }
   if (tid == 1023) off[nb] = partial[1023];
+}
+
+// band of every cell (one thread per cell, binary search in the band offsets)
+__global__ void ag_cell_band_kernel(AgGrid g, int* __restrict__ cell_band) {
+  const int ncells = g.off[g.nb];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncells; c += gridDim.x * blockDim.x) {
+    int lo = 0, hi = g.nb - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (g.off[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    cell_band[c] = lo;
+  }
 }
 
 __global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n, int* __restrict__ cell_of,
@@ -113,21 +126,21 @@ int ag_grid_bands(double delta) {
   return static_cast<int>(nb);
 }
 
-static int64_t ag_grid_cells_ub(int nb) {
+static int64_t ag_grid_cells_ub(int nb, int mult = 1) {
   const double dlat = AG_PI / nb;
-  return static_cast<int64_t>(4.0 * AG_PI / (dlat * dlat) * 1.02) + nb + 64;
+  return (static_cast<int64_t>(4.0 * AG_PI / (dlat * dlat) * 1.02) + nb + 64) * mult;
 }
 
 struct AgBinCarve {
-  int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids;
+  int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids, *cell_band;
   double* win;
   float4* pts;
   void* scan_temp;
   size_t scan_temp_bytes;
 };
 
-static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, bool want_pts, AgBinCarve* c) {
-  const int64_t cells = ag_grid_cells_ub(nb_reserve) + 1;
+static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool want_pts, AgBinCarve* c) {
+  const int64_t cells = ag_grid_cells_ub(nb_reserve, mult) + 1;
   c->ncols = ws.take<int>(nb_reserve);
   c->off = ws.take<int>(nb_reserve + 1);
   c->win = ws.take<double>(nb_reserve);
@@ -138,9 +151,10 @@ static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, bool want_pts,
   c->scan_temp_bytes = ag_scan_i32_temp_bytes(cells);
   c->scan_temp = ws.take<char>(c->scan_temp_bytes);
   c->pts = want_pts ? ws.take<float4>(n) : nullptr;
+  c->cell_band = want_pts ? nullptr : ws.take<int>(cells);  // target grids carry the cell -> band table
 }
 
-static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, AgBinned* out) {
+static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, int mult, AgBinned* out) {
   out->grid.nb = nb;
   out->grid.dlat = AG_PI / nb;
   out->grid.inv_dlat = nb / AG_PI;
@@ -148,23 +162,29 @@ static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, AgBinned* ou
   out->grid.off = c.off;
   out->grid.win = c.win;
   out->n = n;
-  out->ncells_ub = ag_grid_cells_ub(nb);
+  out->ncells_ub = ag_grid_cells_ub(nb, mult);
+  out->cell_band = c.cell_band;
   out->pts = c.pts;
   out->ids = c.ids;
   out->cell_start = c.cell_start;
 }
 
-int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, bool want_pts,
+int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, int mult, bool want_pts,
                   hipStream_t stream, AgBinned* out) {
   if (nb_reserve < nb) nb_reserve = nb;
   AgBinCarve c;
-  ag_bin_carve(ws, n, nb_reserve, want_pts, &c);
+  ag_bin_carve(ws, n, nb_reserve, mult, want_pts, &c);
   if (out == nullptr) return AG_OK;  // sizing pass
-  ag_bin_describe(c, n, nb, out);
+  ag_bin_describe(c, n, nb, mult, out);
   const int64_t ncells_ub = out->ncells_ub;
-  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(1), dim3(1024), stream, nb, out->grid.dlat, c.ncols,
-            c.off, c.win);
+  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(1), dim3(1024), stream, nb, out->grid.dlat, mult,
+            c.ncols, c.off, c.win);
   AG_LAUNCH_CHECK();
+  if (c.cell_band != nullptr) {
+    AG_KERNEL("ag_cell_band_kernel", ag_cell_band_kernel, dim3(ag_blocks(ncells_ub, 256, 4096)), dim3(256), stream,
+              out->grid, c.cell_band);
+    AG_LAUNCH_CHECK();
+  }
   int rc = ag_zero_i32(c.cell_start, ncells_ub + 1, stream);
   if (rc) return rc;
   const int blocks = ag_blocks(n, 256, 16384);
@@ -180,30 +200,34 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
 }
 
 // ---------------------------------------------------------------------------------------------
-// k-NN stage 1: cell tiles in LDS, float32 chord^2, register top-CAP
+// k-NN stage 1: target sub-cell tiles in LDS, float32 chord^2, register top-CAP (float32 only)
 // ---------------------------------------------------------------------------------------------
 #define AG_TILE 256        // staged sources per wave and pass
 #define AG_WAVES_PER_BLOCK 4
 
 struct AgKnnArgs {
-  AgGrid grid;
+  AgGrid sgrid;              // source grid
+  AgGrid tgrid;              // target grid: same bands, `tmult` times the longitude cells
   const float4* spts;        // binned sources
   const int* sstart;         // source cell starts
   const int* tids;           // binned target ids
-  const int* tstart;         // target cell starts (same grid)
+  const int* tstart;         // target cell starts
+  const int* tband;          // band of every target cell
   const float2* tgt;         // target coordinates, original order
   const float2* src;         // source coordinates, original order
   int64_t ns, nt;
   int k;
-  double rg;                 // angular radius the cell tile is guaranteed to cover
+  double rg;                 // angular radius a tile is guaranteed to cover
   float rg_chord2;           // conservative float32 chord^2 of rg
   int32_t* out_src;          // [nt*k]
   double* out_dist;          // [nt*k] or null
+  int* cand_n;               // [nt] per binned target: number of candidates to re-rank in float64 (0 = none)
+  int* cand_ids;             // [CAP][nt] candidate ids, coalesced per rank
   int* queue;                // [nt] targets left to stage 2
   int* queue_count;
+  const struct AgWindow* windows;  // [target cells] precomputed source runs
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
-  unsigned long long* max_bits;  // reference-distance mode: running max of rdist of stage 2 (uint64 bits)
-  double* cell_max;          // reference-distance mode: per-cell max of rdist of stage 1 [ncells_ub]
+  unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
   long long* stats;          // [4]
 };
 
@@ -235,16 +259,14 @@ __device__ __forceinline__ double ag_wave_max_f64(double v) {
   return v;
 }
 
-// Enumerates, for the target cell (band, col), the runs of binned sources within the guaranteed
-// radius of any point of the cell, using the per-band longitude half-width table.
+// Enumerates the runs of binned sources within the guaranteed radius of any point of the
+// longitude interval [lon_lo, lon_hi] of band `band`, using the per-band half-width table.
 template <class F>
-__device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __restrict__ cell_start, int band, int col,
-                                               F&& f) {
-  const int nc = g.ncols[band];
-  const double wlon = AG_TWO_PI / nc;
+__device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __restrict__ cell_start, int band,
+                                               double lon_lo, double lon_hi, F&& f) {
   const double delta = g.win[band];
   const bool full = delta < 0.0;
-  const double lo = col * wlon - delta, hi = (col + 1) * wlon + delta;
+  const double lo = lon_lo - delta, hi = lon_hi + delta;
   const int b0 = max(band - 1, 0), b1 = min(band + 1, g.nb - 1);
   for (int b = b0; b <= b1; ++b) {
     const int ncb = g.ncols[b];
@@ -272,26 +294,48 @@ __device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __res
   }
 }
 
+// A window descriptor: up to AG_WIN_RANGES half-open runs of binned sources, 64 bytes.
+// d[0] = number of runs (-1: too many, enumerate inline), d[1 + 2i], d[2 + 2i] = run i.
+#define AG_WIN_RANGES 7
+struct __attribute__((aligned(64))) AgWindow {
+  int d[16];
+};
+
+// one thread per target cell: the runs of sources that cover the cell (stage 1 then starts with
+// two independent loads instead of a chain of dependent table look-ups per wave)
+__global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
+  const int ncells = a.tgrid.off[a.tgrid.nb];
+  for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += gridDim.x * blockDim.x) {
+    if (a.tstart[cell] >= a.tstart[cell + 1]) continue;
+    const int band = a.tband[cell];
+    const int col = cell - a.tgrid.off[band];
+    const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
+    AgWindow w;
+    int n = 0;
+    ag_cell_window(a.sgrid, a.sstart, band, col * wlon, (col + 1) * wlon, [&](int first, int last) {
+      if (first < last && n < AG_WIN_RANGES) {
+        w.d[1 + 2 * n] = first;
+        w.d[2 + 2 * n] = last;
+      }
+      if (first < last) ++n;
+    });
+    w.d[0] = n <= AG_WIN_RANGES ? n : -1;
+    out[cell] = w;
+  }
+}
+
 template <int CAP>
 __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(AgKnnArgs a) {
   __shared__ float4 tile_all[AG_WAVES_PER_BLOCK][AG_TILE];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = ag_lane();
   float4* tile = tile_all[wave];
-  const int ncells = a.grid.off[a.grid.nb];
+  const int ncells = a.tgrid.off[a.tgrid.nb];
   const int cell = __builtin_amdgcn_readfirstlane(blockIdx.x * AG_WAVES_PER_BLOCK + wave);
   if (cell >= ncells) return;
   const int t0 = a.tstart[cell], t1 = a.tstart[cell + 1];
-  if (t0 >= t1) {
-    if (a.self_query && lane == 0) a.cell_max[cell] = 0.0;
-    return;
-  }
-  double cell_max = 0.0;
-
-  // band of this cell from its first target (every target of a cell shares the band)
-  const float2 first = a.tgt[a.tids[t0]];
-  const int band = __builtin_amdgcn_readfirstlane(ag_band_of(a.grid, static_cast<double>(first.x)));
-  const int col = cell - a.grid.off[band];
+  if (t0 >= t1) return;
+  const AgWindow win = a.windows[cell];
   const int k = a.k;
 
   for (int tb = t0; tb < t1; tb += 64) {
@@ -299,10 +343,9 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     const bool active = ti < t1;
     int tid = -1;
     float3 tu = make_float3(0.f, 0.f, 0.f);
-    float2 tp = make_float2(0.f, 0.f);
     if (active) {
       tid = a.tids[ti];
-      tp = a.tgt[tid];
+      const float2 tp = a.tgt[tid];
       tu = ag_unit_vec_f32(tp.x, tp.y);
     }
     float bd[CAP];
@@ -326,7 +369,7 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     };
-    ag_cell_window(a.grid, a.sstart, band, col, [&](int first_pos, int last_pos) {
+    auto stage_run = [&](int first_pos, int last_pos) {
       int pos = first_pos;
       while (pos < last_pos) {
         const int take = min(last_pos - pos, AG_TILE - fill);
@@ -338,7 +381,17 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
           fill = 0;
         }
       }
-    });
+    };
+    if (win.d[0] >= 0) {
+#pragma unroll
+      for (int r = 0; r < AG_WIN_RANGES; ++r)
+        if (r < win.d[0]) stage_run(win.d[1 + 2 * r], win.d[2 + 2 * r]);
+    } else {
+      const int band = a.tband[cell];
+      const int col = cell - a.tgrid.off[band];
+      const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
+      ag_cell_window(a.sgrid, a.sstart, band, col * wlon, (col + 1) * wlon, stage_run);
+    }
     if (fill > 0) scan_tile(fill);
 
     // ---- classify -------------------------------------------------------------------------
@@ -347,14 +400,21 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     // than each of the first k entries [x - err(x) >= dk + ek for x >= thr_hi], so the exact k nearest
     // are among the entries up to the last one below thr_hi ("cluster end" c1).  The list is
     //   final      if c1 is the k-th entry itself and the first k gaps exceed their error bounds,
-    //   re-ranked  in float64 (scikit-learn's formula, ties on ids) if c1 lies inside the list,
-    //   queued     if the cluster may run past the list or the k-th entry is not provably inside
-    //              the region the tile covers.
+    //   re-ranked  in float64 by ag_knn_resolve_kernel if c1 lies inside the list,
+    //   queued     for stage 2 if the cluster may run past the list or the k-th entry is not provably
+    //              inside the region the tile covers.
     constexpr bool RESOLVE = (CAP <= 12);
-    const float dk = bd[k - 1];
+    float dk = 3.0e38f;
+    int ik = -1;
+#pragma unroll
+    for (int j = 0; j < CAP; ++j)
+      if (j == k - 1) {
+        dk = bd[j];
+        ik = bi[j];
+      }
     const float ek = ag_chord2_err(dk);
     const float thr_hi = dk + 3.0f * ek + 4.0e-12f;
-    const bool have_k = active && (bi[k - 1] >= 0);
+    const bool have_k = active && (ik >= 0);
     bool queued = active && !have_k;
     int c1 = k - 1;
 #pragma unroll
@@ -372,67 +432,18 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       if (!RESOLVE && exact) queued = true;
     }
     const bool done = have_k && !queued;
-
-    if constexpr (RESOLVE) {
-      double rr[CAP];  // float64 rdist of the entries (only where needed)
+    if (done && !exact) {
+      int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
 #pragma unroll
-      for (int j = 0; j < CAP; ++j) rr[j] = 1.0e300;
-      if (done && (exact || a.out_dist != nullptr)) {
-        const int upto = exact ? c1 : k - 1;
+      for (int j = 0; j < CAP; ++j)
+        if (j < k) o[j] = bi[j];
+    }
+    if (RESOLVE && active) {
+      const bool rec = done && exact;
+      a.cand_n[ti] = rec ? c1 + 1 : 0;
+      if (rec) {
 #pragma unroll
-        for (int j = 0; j < CAP; ++j) {
-          if (j <= upto) {
-            const float2 p = a.src[bi[j]];
-            rr[j] = ag_rdist(tp.x, tp.y, p.x, p.y);
-          }
-        }
-      }
-      if (done && exact) {
-        // selection sort of the (rdist, id) pairs, fully unrolled so everything stays in registers
-#pragma unroll
-        for (int i = 0; i < CAP - 1; ++i) {
-#pragma unroll
-          for (int j = i + 1; j < CAP; ++j) {
-            const bool sw = ag_pair_less(rr[j], bi[j], rr[i], bi[i]);
-            const double r0 = sw ? rr[j] : rr[i], r1 = sw ? rr[i] : rr[j];
-            const int i0 = sw ? bi[j] : bi[i], i1 = sw ? bi[i] : bi[j];
-            rr[i] = r0;
-            rr[j] = r1;
-            bi[i] = i0;
-            bi[j] = i1;
-          }
-        }
-      }
-      if (a.self_query) {
-        const double r = done ? rr[1] : 0.0;
-        cell_max = fmax(cell_max, ag_wave_max_f64(r));
-      } else if (done) {
-        int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
-#pragma unroll
-        for (int j = 0; j < CAP; ++j)
-          if (j < k) o[j] = bi[j];
-        if (a.out_dist != nullptr) {
-          double* od = a.out_dist + static_cast<int64_t>(tid) * k;
-#pragma unroll
-          for (int j = 0; j < CAP; ++j)
-            if (j < k) od[j] = ag_rdist_to_dist(rr[j]);
-        }
-      }
-    } else {
-      if (done) {
-        int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
-#pragma unroll
-        for (int j = 0; j < CAP; ++j)
-          if (j < k) o[j] = bi[j];
-        if (a.out_dist != nullptr) {
-          double* od = a.out_dist + static_cast<int64_t>(tid) * k;
-#pragma unroll
-          for (int j = 0; j < CAP; ++j)
-            if (j < k) {
-              const float2 p = a.src[bi[j]];
-              od[j] = ag_rdist_to_dist(ag_rdist(tp.x, tp.y, p.x, p.y));
-            }
-        }
+        for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.nt + ti] = bi[j];
       }
     }
     if (queued) {
@@ -440,7 +451,77 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       a.queue[slot] = tid;
     }
   }
-  if (a.self_query && lane == 0) a.cell_max[cell] = cell_max;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-NN stage 1b: float64 re-ranking of the candidate lists stage 1 could not order in float32
+// (one thread per binned target, scikit-learn's rdist, ties on ids)
+// ---------------------------------------------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
+  __shared__ double sh[4];
+  double my_max = 0.0;
+  const int k = a.k;
+  for (int64_t ti = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; ti < a.nt; ti += int64_t(gridDim.x) * blockDim.x) {
+    const int n = a.cand_n[ti];
+    if (n == 0) continue;
+    const int tid = a.tids[ti];
+    const float2 tp = a.tgt[tid];
+    double rr[CAP];
+    int bi[CAP];
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) {
+      rr[j] = 1.0e300;
+      bi[j] = 0x7fffffff;
+      if (j < n) {
+        bi[j] = a.cand_ids[static_cast<int64_t>(j) * a.nt + ti];
+        const float2 p = a.src[bi[j]];
+        rr[j] = ag_rdist(tp.x, tp.y, p.x, p.y);
+      }
+    }
+    // selection sort of the (rdist, id) pairs, fully unrolled so everything stays in registers
+#pragma unroll
+    for (int i = 0; i < CAP - 1; ++i) {
+#pragma unroll
+      for (int j = i + 1; j < CAP; ++j) {
+        const bool sw = ag_pair_less(rr[j], bi[j], rr[i], bi[i]);
+        const double r0 = sw ? rr[j] : rr[i], r1 = sw ? rr[i] : rr[j];
+        const int i0 = sw ? bi[j] : bi[i], i1 = sw ? bi[i] : bi[j];
+        rr[i] = r0;
+        rr[j] = r1;
+        bi[i] = i0;
+        bi[j] = i1;
+      }
+    }
+    if (a.self_query) {
+      my_max = fmax(my_max, rr[1]);
+    } else {
+      int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
+#pragma unroll
+      for (int j = 0; j < CAP; ++j)
+        if (j < k) o[j] = bi[j];
+    }
+  }
+  if (a.self_query) {
+    my_max = ag_wave_max_f64(my_max);
+    if (ag_lane() == 0) sh[threadIdx.x >> 6] = my_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double m = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+      if (m > 0.0) atomicMax(a.max_bits, static_cast<unsigned long long>(__double_as_longlong(m)));
+    }
+  }
+}
+
+// distances of the final neighbour table (only when the caller asks for them)
+__global__ void ag_knn_dist_kernel(AgKnnArgs a) {
+  const int64_t total = a.nt * a.k;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t t = i / a.k;
+    const float2 tp = a.tgt[t];
+    const float2 sp = a.src[a.out_src[i]];
+    a.out_dist[i] = ag_rdist_to_dist(ag_rdist(tp.x, tp.y, sp.x, sp.y));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -488,7 +569,7 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       for (int j = 0; j < k; ++j) {
         double best_r = 1.0e300;
         int best_i = 0x7fffffff;
-        ag_for_each_range(a.grid, a.sstart, tlat, tlat, tlonw, tlonw, Rw, [&](int first, int last) {
+        ag_for_each_range(a.sgrid, a.sstart, tlat, tlat, tlonw, tlonw, Rw, [&](int first, int last) {
           for (int p = first + lane; p < last; p += 64) {
             const int id = __float_as_int(a.spts[p].w);
             const float2 sp = a.src[id];
@@ -515,7 +596,6 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
             atomicMax(a.max_bits, static_cast<unsigned long long>(__double_as_longlong(m.r)));
         } else if (lane == 0) {
           a.out_src[static_cast<int64_t>(tid) * k + j] = m.id;
-          if (a.out_dist != nullptr) a.out_dist[static_cast<int64_t>(tid) * k + j] = ag_rdist_to_dist(m.r);
         }
       }
       if (covered || whole) break;
@@ -539,20 +619,9 @@ __global__ void ag_knn_init_kernel(int* queue_count, unsigned long long* max_bit
   }
 }
 
-__global__ __launch_bounds__(1024) void ag_maxdist_finish_kernel(AgGrid g, const double* __restrict__ cell_max,
-                                                                 const unsigned long long* max_bits, double* out) {
-  __shared__ double sh[16];
-  const int ncells = g.off[g.nb];
-  double r = 0.0;
-  for (int c = threadIdx.x; c < ncells; c += blockDim.x) r = fmax(r, cell_max[c]);
-  r = ag_wave_max_f64(r);
-  if (ag_lane() == 0) sh[threadIdx.x >> 6] = r;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) r = fmax(r, sh[w]);
-    r = fmax(r, __longlong_as_double(static_cast<long long>(*max_bits)));
-    *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
-  }
+__global__ void ag_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
+  const double r = __longlong_as_double(static_cast<long long>(*max_bits));
+  *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
 }
 
 // cell size for a k-NN search over ns quasi-uniform sources: the disc of radius delta holds
@@ -564,42 +633,71 @@ static double ag_knn_delta(int64_t ns, int k) {
   return d;
 }
 
+// list capacity of stage 1: k entries, the (k+1)-th as the boundary witness, room for an ambiguous cluster
+static int ag_knn_cap(int k, bool self_query) {
+  if (self_query) return 8;
+  const int need = k + 2;
+  const int caps[] = {3, 5, 8, 12, 18, 34, AG_KNN_MAX_K + 2};
+  for (int c : caps)
+    if (need <= c) return c;
+  return AG_KNN_MAX_K + 2;
+}
+
+// longitude-cell multiplier of the target grid: about 48 targets per target cell
+static int ag_knn_tmult(int64_t nt, int nb) {
+  const double dlat = AG_PI / nb;
+  const double per_cell = static_cast<double>(nt) / (4.0 * AG_PI / (dlat * dlat));
+  int m = static_cast<int>(ceil(per_cell / 48.0));
+  if (m < 1) m = 1;
+  if (m > 64) m = 64;
+  return m;
+}
+
 struct AgKnnWs {
   AgBinned src, tgt;
+  int tmult;
   int* queue;
   int* queue_count;
   unsigned long long* max_bits;
-  double* cell_max;
+  int* cand_n;
+  int* cand_ids;
+  struct AgWindow* windows;
 };
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
                           bool self_query, hipStream_t stream, AgKnnWs* w) {
   const int nb = ag_grid_bands(ag_knn_delta(ns, k));
-  int rc = ag_bin_points(c, d_src, ns, nb, nb, true, stream, w ? &w->src : nullptr);
+  const int tmult = ag_knn_tmult(nt, nb);
+  int rc = ag_bin_points(c, d_src, ns, nb, nb, 1, true, stream, w ? &w->src : nullptr);
   if (rc) return rc;
-  if (!self_query) {
-    rc = ag_bin_points(c, d_tgt, nt, nb, nb, false, stream, w ? &w->tgt : nullptr);
-    if (rc) return rc;
-  } else if (w) {
-    w->tgt = w->src;
-  }
+  rc = ag_bin_points(c, d_tgt, nt, nb, nb, tmult, false, stream, w ? &w->tgt : nullptr);
+  if (rc) return rc;
+  const int cap = ag_knn_cap(k, self_query);
   int* queue = c.take<int>(nt);
   int* queue_count = c.take<int>(4);
   unsigned long long* max_bits = c.take<unsigned long long>(2);
-  double* cell_max = self_query ? c.take<double>(ag_grid_cells_ub(nb) + 1) : nullptr;
+  int* cand_n = cap <= 12 ? c.take<int>(nt) : nullptr;
+  int* cand_ids = cap <= 12 ? c.take<int>(nt * cap) : nullptr;
+  AgWindow* windows = c.take<AgWindow>(ag_grid_cells_ub(nb, tmult) + 1);
   if (w) {
-    w->cell_max = cell_max;
+    w->windows = windows;
+    w->tmult = tmult;
     w->queue = queue;
     w->queue_count = queue_count;
     w->max_bits = max_bits;
+    w->cand_n = cand_n;
+    w->cand_ids = cand_ids;
   }
   return AG_OK;
 }
 
 template <int CAP>
-static void ag_launch_cell_kernel(const AgKnnArgs& a, int64_t ncells_ub, hipStream_t stream) {
-  const int blocks = ag_blocks(ncells_ub, AG_WAVES_PER_BLOCK);
+static void ag_launch_stage1(const AgKnnArgs& a, int64_t tcells_ub, hipStream_t stream) {
+  const int blocks = ag_blocks(tcells_ub, AG_WAVES_PER_BLOCK);
   AG_KERNEL("ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
+  if constexpr (CAP <= 12) {
+    AG_KERNEL("ag_knn_resolve_kernel", ag_knn_resolve_kernel<CAP>, dim3(ag_blocks(a.nt, 256, 8192)), dim3(256), stream, a);
+  }
 }
 
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
@@ -617,11 +715,13 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   AG_LAUNCH_CHECK();
 
   AgKnnArgs a;
-  a.grid = w.src.grid;
+  a.sgrid = w.src.grid;
+  a.tgrid = w.tgt.grid;
   a.spts = w.src.pts;
   a.sstart = w.src.cell_start;
   a.tids = w.tgt.ids;
   a.tstart = w.tgt.cell_start;
+  a.tband = w.tgt.cell_band;
   a.tgt = reinterpret_cast<const float2*>(d_tgt);
   a.src = reinterpret_cast<const float2*>(d_src);
   a.ns = ns;
@@ -634,29 +734,36 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   }
   a.out_src = d_out_src;
   a.out_dist = d_out_dist;
+  a.cand_n = w.cand_n;
+  a.cand_ids = w.cand_ids;
   a.queue = w.queue;
   a.queue_count = w.queue_count;
+  a.windows = w.windows;
   a.self_query = self_query ? 1 : 0;
   a.max_bits = w.max_bits;
-  a.cell_max = w.cell_max;
   a.stats = reinterpret_cast<long long*>(d_stats);
 
-  const int64_t ncu = w.src.ncells_ub;
-  // list capacity: k entries, the (k+1)-th as the boundary witness, and room for an ambiguous cluster
-  if (self_query) ag_launch_cell_kernel<8>(a, ncu, stream);
-  else if (k + 2 <= 3) ag_launch_cell_kernel<3>(a, ncu, stream);
-  else if (k + 2 <= 5) ag_launch_cell_kernel<5>(a, ncu, stream);
-  else if (k + 2 <= 8) ag_launch_cell_kernel<8>(a, ncu, stream);
-  else if (k + 2 <= 12) ag_launch_cell_kernel<12>(a, ncu, stream);
-  else if (k + 2 <= 18) ag_launch_cell_kernel<18>(a, ncu, stream);
-  else if (k + 2 <= 34) ag_launch_cell_kernel<34>(a, ncu, stream);
-  else ag_launch_cell_kernel<AG_KNN_MAX_K + 2>(a, ncu, stream);
+  const int64_t tcu = w.tgt.ncells_ub;
+  AG_KERNEL("ag_knn_window_kernel", ag_knn_window_kernel, dim3(ag_blocks(tcu, 256, 8192)), dim3(256), stream, a,
+            w.windows);
+  AG_LAUNCH_CHECK();
+  switch (ag_knn_cap(k, self_query)) {
+    case 3: ag_launch_stage1<3>(a, tcu, stream); break;
+    case 5: ag_launch_stage1<5>(a, tcu, stream); break;
+    case 8: ag_launch_stage1<8>(a, tcu, stream); break;
+    case 12: ag_launch_stage1<12>(a, tcu, stream); break;
+    case 18: ag_launch_stage1<18>(a, tcu, stream); break;
+    case 34: ag_launch_stage1<34>(a, tcu, stream); break;
+    default: ag_launch_stage1<AG_KNN_MAX_K + 2>(a, tcu, stream); break;
+  }
   AG_LAUNCH_CHECK();
   AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
   AG_LAUNCH_CHECK();
   if (self_query) {
-    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1024), stream, w.src.grid,
-              w.cell_max, w.max_bits, d_out_max);
+    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1), stream, w.max_bits, d_out_max);
+    AG_LAUNCH_CHECK();
+  } else if (d_out_dist != nullptr) {
+    AG_KERNEL("ag_knn_dist_kernel", ag_knn_dist_kernel, dim3(ag_blocks(nt * k, 256, 16384)), dim3(256), stream, a);
     AG_LAUNCH_CHECK();
   }
   return AG_OK;
@@ -827,15 +934,15 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
   const int nb_reserve = ag_grid_bands(sqrt(4.0 * AG_PI / static_cast<double>(ns)));
   const int nb = ag_grid_bands(ag_radius_delta(ns, radius));
   if (w == nullptr) {
-    ag_bin_points(c, nullptr, ns, nb_reserve, nb_reserve, true, stream, nullptr);
+    ag_bin_points(c, nullptr, ns, nb_reserve, nb_reserve, 1, true, stream, nullptr);
   } else if (build) {
-    int rc = ag_bin_points(c, d_src, ns, nb, nb_reserve, true, stream, &w->src);
+    int rc = ag_bin_points(c, d_src, ns, nb, nb_reserve, 1, true, stream, &w->src);
     if (rc) return rc;
   } else {
     // descriptor of the grid the count pass built in this workspace (same carve, no kernels)
     AgBinCarve bc;
-    ag_bin_carve(c, ns, nb_reserve, true, &bc);
-    ag_bin_describe(bc, ns, nb, &w->src);
+    ag_bin_carve(c, ns, nb_reserve, 1, true, &bc);
+    ag_bin_describe(bc, ns, nb, 1, &w->src);
   }
   const size_t stb = ag_scan_i64_temp_bytes(nt);
   void* st = c.take<char>(stb);
