@@ -28,15 +28,14 @@ SIGNATURES = {
     "ag_radius_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ag_radius_count": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, _P, c_size_t, _P]),
     "ag_radius_fill": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, _P, _P, _P, c_size_t, _P]),
-    "ag_icosphere_sizes": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "ag_icosphere_sizes": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "ag_icosphere_workspace_bytes": (c_size_t, [c_int]),
-    "ag_icosphere": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_icosphere": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "ag_multiscale_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "ag_multiscale_count": (c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_multiscale_count": (
+        c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "ag_multiscale_fill": (
-        c_int,
-        [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, _P, _P, c_int64, _P, _P, _P, c_size_t, _P],
-    ),
+        c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "ag_edge_attrs": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P]),
     "ag_normalise_workspace_bytes": (c_size_t, [c_int64]),
     "ag_normalise": (c_int, [_P, c_int64, c_int, c_int, _P, c_size_t, _P]),

@@ -28,6 +28,8 @@ __constant__ int ag_ico_faces[20][3] = {{0, 11, 5}, {0, 5, 1},  {0, 1, 7},   {0,
 static inline int64_t ag_ico_V(int l) { return 10 * (int64_t(1) << (2 * l)) + 2; }
 static inline int64_t ag_ico_F(int l) { return 20 * (int64_t(1) << (2 * l)); }
 static inline int64_t ag_ico_E(int l) { return 30 * (int64_t(1) << (2 * l)); }
+// offset of level l in the concatenated per-level unique-edge array: sum of E_j for j < l
+static inline int64_t ag_ico_edge_offset(int l) { return 10 * ((int64_t(1) << (2 * l)) - 1); }
 
 __global__ void ag_ico_init_kernel(double* __restrict__ xyz, int32_t* __restrict__ faces) {
   const int i = threadIdx.x;
@@ -99,6 +101,29 @@ __global__ void ag_ico_subdivide_kernel(const int32_t* __restrict__ fin, int64_t
     o[3] = m0; o[4] = b;  o[5] = m1;
     o[6] = m2; o[7] = m1; o[8] = c;
     o[9] = m0; o[10] = m1; o[11] = m2;
+  }
+}
+
+// unique edges of level R from the last subdivision, no sort: every level-(R-1) edge (a,b) with
+// midpoint m gives (a,m) and (b,m); the central child (m0,m1,m2) of every parent face gives its 3 sides
+__global__ void ag_ico_final_edges_kernel(const uint64_t* __restrict__ parent_edges, int64_t Eu, int64_t V,
+                                          const int32_t* __restrict__ child_faces, int64_t F_parent,
+                                          uint64_t* __restrict__ out) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < Eu + F_parent; i += int64_t(gridDim.x) * blockDim.x) {
+    if (i < Eu) {
+      const uint64_t k = parent_edges[i];
+      const int a = static_cast<int>(static_cast<uint32_t>(k)), b = static_cast<int>(static_cast<uint32_t>(k >> 32));
+      const int m = static_cast<int>(V + i);
+      out[2 * i] = ag_edge_key(a, m);
+      out[2 * i + 1] = ag_edge_key(b, m);
+    } else {
+      const int64_t f = i - Eu;
+      const int m0 = child_faces[12 * f + 9], m1 = child_faces[12 * f + 10], m2 = child_faces[12 * f + 11];
+      uint64_t* o = out + 2 * Eu + 3 * f;
+      o[0] = ag_edge_key(m0, m1);
+      o[1] = ag_edge_key(m1, m2);
+      o[2] = ag_edge_key(m2, m0);
+    }
   }
 }
 
@@ -197,22 +222,25 @@ static int ag_vertex_bits(int l) {
   return bits;
 }
 
-// unique edges of `faces` (level l) into w.uniq
-static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, hipStream_t s) {
+// unique edges of `faces` (level l) into `uniq`
+static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, uint64_t* uniq, hipStream_t s) {
   const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l);
-  AG_KERNEL("ag_ico_edge_keys_kernel", ag_ico_edge_keys_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), s, faces, F, w.keys_a);
+  AG_KERNEL("ag_ico_edge_keys_kernel", ag_ico_edge_keys_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), s, faces,
+            F, w.keys_a);
   AG_LAUNCH_CHECK();
   int rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, 3 * F, 0, 32 + ag_vertex_bits(l), s);
   if (rc) return rc;
-  AG_KERNEL("ag_ico_unique_kernel", ag_ico_unique_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, w.keys_b, Eu, w.uniq, w.error_flag);
+  AG_KERNEL("ag_ico_unique_kernel", ag_ico_unique_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, w.keys_b, Eu,
+            uniq, w.error_flag);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
 
-extern "C" int ag_icosphere_sizes(int R, int64_t* V, int64_t* F) {
+extern "C" int ag_icosphere_sizes(int R, int64_t* V, int64_t* F, int64_t* E_all) {
   AG_REQUIRE(R >= 0 && R <= AG_ICO_MAX_LEVEL, "ag_icosphere: resolution %d outside [0, %d]", R, AG_ICO_MAX_LEVEL);
   if (V) *V = ag_ico_V(R);
   if (F) *F = ag_ico_F(R);
+  if (E_all) *E_all = ag_ico_edge_offset(R + 1);
   return AG_OK;
 }
 
@@ -225,7 +253,7 @@ extern "C" size_t ag_icosphere_workspace_bytes(int R) {
 }
 
 extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_t* d_order, int32_t* d_rank,
-                            void* d_ws, size_t ws_bytes, void* stream) {
+                            uint64_t* d_level_edges, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(R >= 0 && R <= AG_ICO_MAX_LEVEL, "ag_icosphere: resolution %d outside [0, %d]", R, AG_ICO_MAX_LEVEL);
   AG_REQUIRE(d_xyz && d_faces && d_latlon && d_order && d_rank && d_ws, "ag_icosphere: null pointer");
   if (ws_bytes < ag_icosphere_workspace_bytes(R)) return ag_fail(AG_ERR_WORKSPACE, "ag_icosphere: workspace too small");
@@ -237,22 +265,37 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   // ping-pong between the caller's face buffer and the workspace so that level R lands in d_faces
   int32_t* cur = (R % 2 == 0) ? d_faces : w.faces_a;
   int32_t* nxt = (R % 2 == 0) ? w.faces_a : d_faces;
-  { int rcz = ag_zero_i32(w.error_flag, 1, s); if (rcz) return rcz; }
+  int rc = ag_zero_i32(w.error_flag, 1, s);
+  if (rc) return rc;
   AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, d_xyz, cur);
   AG_LAUNCH_CHECK();
   for (int l = 0; l < R; ++l) {
     const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
-    int rc = ag_topo_unique_edges(w, cur, l, s);
+    // the unique edges of level l go straight into the per-level edge array when the caller wants it
+    uint64_t* uniq = d_level_edges ? d_level_edges + ag_ico_edge_offset(l) : w.uniq;
+    rc = ag_topo_unique_edges(w, cur, l, uniq, s);
     if (rc) return rc;
-    AG_KERNEL("ag_ico_midpoints_kernel", ag_ico_midpoints_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, w.uniq, Eu, V, d_xyz);
+    AG_KERNEL("ag_ico_midpoints_kernel", ag_ico_midpoints_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, uniq,
+              Eu, V, d_xyz);
     AG_LAUNCH_CHECK();
-    AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F, w.uniq, Eu, static_cast<int>(V), nxt);
+    AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F,
+              uniq, Eu, static_cast<int>(V), nxt);
     AG_LAUNCH_CHECK();
-    AG_KERNEL("ag_ico_project_kernel", ag_ico_project_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), s, d_xyz, V + Eu);
+    AG_KERNEL("ag_ico_project_kernel", ag_ico_project_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), s, d_xyz,
+              V + Eu);
     AG_LAUNCH_CHECK();
+    if (d_level_edges && l == R - 1) {
+      AG_KERNEL("ag_ico_final_edges_kernel", ag_ico_final_edges_kernel, dim3(ag_blocks(Eu + F, 256, 8192)), dim3(256),
+                s, uniq, Eu, V, nxt, F, d_level_edges + ag_ico_edge_offset(R));
+      AG_LAUNCH_CHECK();
+    }
     int32_t* t = cur;
     cur = nxt;
     nxt = t;
+  }
+  if (d_level_edges && R == 0) {
+    rc = ag_topo_unique_edges(w, cur, 0, d_level_edges, s);
+    if (rc) return rc;
   }
   const int64_t V = ag_ico_V(R);
   const int vb = ag_blocks(V, 256, 8192);
@@ -262,13 +305,15 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   uint64_t* sorted0 = w.uniq;  // E_R >= V_R entries
   AG_KERNEL("ag_ico_order_keys0_kernel", ag_ico_order_keys0_kernel, dim3(vb), dim3(256), s, latlon, V, w.keys_a);
   AG_LAUNCH_CHECK();
-  int rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, sorted0, V, 0, 64, s);
+  rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, sorted0, V, 0, 64, s);
   if (rc) return rc;
-  AG_KERNEL("ag_ico_order_keys1_kernel", ag_ico_order_keys1_kernel, dim3(vb), dim3(256), s, latlon, V, sorted0, w.keys_a);
+  AG_KERNEL("ag_ico_order_keys1_kernel", ag_ico_order_keys1_kernel, dim3(vb), dim3(256), s, latlon, V, sorted0,
+            w.keys_a);
   AG_LAUNCH_CHECK();
   rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, V, 0, 64, s);
   if (rc) return rc;
-  AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, sorted0, w.keys_b, latlon, V, reinterpret_cast<float2*>(d_latlon), d_order, d_rank);
+  AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, sorted0, w.keys_b, latlon,
+            V, reinterpret_cast<float2*>(d_latlon), d_order, d_rank);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -279,6 +324,29 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
 #define AG_NO_PAIR 0xffffffffffffffffull
 
 static inline int ag_hops_capacity(int x_hops) { return 3 * x_hops * (x_hops + 1); }
+
+__device__ __forceinline__ uint64_t ag_pair_key(int src_node, int tgt_node) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(tgt_node)) << 32) | static_cast<uint32_t>(src_node);
+}
+
+// x_hops == 1: both directions of every (active) mesh edge, one fixed pair of slots per edge
+__global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ edges, int64_t Eu, const uint8_t* __restrict__ active,
+                                        const int32_t* __restrict__ rank, uint64_t* __restrict__ pairs) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < Eu; i += int64_t(gridDim.x) * blockDim.x) {
+    const uint64_t k = edges[i];
+    const int a = static_cast<int>(static_cast<uint32_t>(k)), b = static_cast<int>(static_cast<uint32_t>(k >> 32));
+    uint64_t p0 = AG_NO_PAIR, p1 = AG_NO_PAIR;
+    if (active == nullptr || (active[a] && active[b])) {
+      const int ra = rank[a], rb = rank[b];
+      if (ra >= 0 && rb >= 0) {
+        p0 = ag_pair_key(ra, rb);
+        p1 = ag_pair_key(rb, ra);
+      }
+    }
+    pairs[2 * i] = p0;
+    pairs[2 * i + 1] = p1;
+  }
+}
 
 __global__ void ag_ms_adjacency_kernel(const uint64_t* __restrict__ uniq, int64_t Eu, const uint8_t* __restrict__ active,
                                        int* __restrict__ deg, int* __restrict__ adj) {
@@ -293,7 +361,7 @@ __global__ void ag_ms_adjacency_kernel(const uint64_t* __restrict__ uniq, int64_
   }
 }
 
-// one thread per level vertex: breadth-first expansion to x_hops, one fixed slot per possible neighbour
+// x_hops > 1, one thread per level vertex: breadth-first expansion, one fixed slot per possible neighbour
 template <int CAP>
 __global__ __launch_bounds__(64) void ag_ms_pairs_kernel(int64_t V, int x_hops, const int* __restrict__ deg,
                                                          const int* __restrict__ adj, const int32_t* __restrict__ rank,
@@ -333,7 +401,7 @@ __global__ __launch_bounds__(64) void ag_ms_pairs_kernel(int64_t V, int x_hops, 
     uint64_t key = AG_NO_PAIR;
     if (j < n && rv >= 0) {
       const int ru = rank[list[j]];
-      if (ru >= 0) key = (static_cast<uint64_t>(static_cast<uint32_t>(ru)) << 32) | static_cast<uint32_t>(rv);
+      if (ru >= 0) key = ag_pair_key(rv, ru);
     }
     out[j] = key;
   }
@@ -366,9 +434,8 @@ __global__ void ag_ms_emit_kernel(const uint64_t* __restrict__ sorted, const int
 }
 
 struct AgMsWs {
-  AgTopoWs topo;
-  int* deg;           // [V_R]
-  int* adj;           // [V_R * 6]
+  int* deg;           // [V_R]        (x_hops > 1)
+  int* adj;           // [V_R * 6]    (x_hops > 1)
   uint64_t* pairs_a;  // [total slots]
   uint64_t* pairs_b;
   int64_t* offsets;   // [total slots + 1]
@@ -377,16 +444,19 @@ struct AgMsWs {
   int64_t slots;
 };
 
+static int64_t ag_ms_level_slots(int l, int x_hops) {
+  return x_hops == 1 ? 2 * ag_ico_E(l) : ag_ico_V(l) * ag_hops_capacity(x_hops);
+}
+
 static int ag_ms_carve(AgCarver& c, int R, const int32_t* levels, int nlevels, int x_hops, AgMsWs* w) {
   AgMsWs m;
-  ag_topo_carve(c, R, true, &m.topo);
-  m.deg = c.take<int>(ag_ico_V(R));
-  m.adj = c.take<int>(ag_ico_V(R) * AG_MAX_DEG);
+  m.deg = x_hops > 1 ? c.take<int>(ag_ico_V(R)) : nullptr;
+  m.adj = x_hops > 1 ? c.take<int>(ag_ico_V(R) * AG_MAX_DEG) : nullptr;
   // sizing without the level list (levels == nullptr) assumes the nlevels finest levels
   int64_t slots = 0;
   for (int i = 0; i < nlevels; ++i) {
     const int l = levels ? levels[i] : (R - i < 0 ? 0 : R - i);
-    slots += ag_ico_V(l) * ag_hops_capacity(x_hops);
+    slots += ag_ms_level_slots(l, x_hops);
   }
   m.slots = slots;
   m.pairs_a = c.take<uint64_t>(slots);
@@ -421,65 +491,51 @@ static int ag_ms_check(int R, const int32_t* levels, int nlevels, int x_hops) {
 template <int CAP>
 static void ag_ms_launch_pairs(int64_t V, int x_hops, const AgMsWs& m, const int32_t* rank, uint64_t* pairs,
                                hipStream_t s) {
-  AG_KERNEL("ag_ms_pairs_kernel", ag_ms_pairs_kernel<CAP>, dim3(ag_blocks(V, 64)), dim3(64), s, V, x_hops, m.deg, m.adj, rank, pairs);
+  AG_KERNEL("ag_ms_pairs_kernel", ag_ms_pairs_kernel<CAP>, dim3(ag_blocks(V, 64)), dim3(64), s, V, x_hops, m.deg, m.adj,
+            rank, pairs);
 }
 
 extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
-                                   const uint8_t* d_active, int64_t* d_num_edges, void* d_ws, size_t ws_bytes,
-                                   void* stream) {
+                                   const uint8_t* d_active, const uint64_t* d_level_edges, int64_t* d_num_edges,
+                                   void* d_ws, size_t ws_bytes, void* stream) {
   int rc = ag_ms_check(R, levels, nlevels, x_hops);
   if (rc) return rc;
-  AG_REQUIRE(d_rank && d_num_edges && d_ws, "ag_multiscale_count: null pointer");
-  {
-    AgCarver sizing(nullptr);
-    ag_ms_carve(sizing, R, levels, nlevels, x_hops, nullptr);
-    if (ws_bytes < sizing.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_count: workspace too small");
-  }
+  AG_REQUIRE(d_rank && d_level_edges && d_num_edges && d_ws, "ag_multiscale_count: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AgCarver c(d_ws);
   AgMsWs m;
   ag_ms_carve(c, R, levels, nlevels, x_hops, &m);
+  if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_count: workspace too small");
   const int cap = ag_hops_capacity(x_hops);
-
-  int32_t* cur = m.topo.faces_a;
-  int32_t* nxt = m.topo.faces_b;
-  { int rcz = ag_zero_i32(m.topo.error_flag, 1, s); if (rcz) return rcz; }
-  AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, static_cast<double*>(nullptr), cur);
-  AG_LAUNCH_CHECK();
-  int max_level = 0;
-  for (int i = 0; i < nlevels; ++i) max_level = levels[i] > max_level ? levels[i] : max_level;
   int64_t slot_base = 0;
-  for (int l = 0; l <= max_level; ++l) {
-    const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
-    rc = ag_topo_unique_edges(m.topo, cur, l, s);
-    if (rc) return rc;
-    bool wanted = false;
-    for (int i = 0; i < nlevels; ++i) wanted = wanted || (levels[i] == l);
-    if (wanted) {
-      { int rcz = ag_zero_i32(m.deg, V, s); if (rcz) return rcz; }
-      AG_KERNEL("ag_ms_adjacency_kernel", ag_ms_adjacency_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, m.topo.uniq, Eu, d_active, m.deg, m.adj);
+  for (int i = 0; i < nlevels; ++i) {
+    const int l = levels[i];
+    const int64_t Eu = ag_ico_E(l), V = ag_ico_V(l);
+    const uint64_t* edges = d_level_edges + ag_ico_edge_offset(l);
+    uint64_t* pairs = m.pairs_a + slot_base;
+    if (x_hops == 1) {
+      AG_KERNEL("ag_ms_edge_pairs_kernel", ag_ms_edge_pairs_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, edges,
+                Eu, d_active, d_rank, pairs);
       AG_LAUNCH_CHECK();
-      uint64_t* pairs = m.pairs_a + slot_base;
-      if (cap <= 6) ag_ms_launch_pairs<6>(V, x_hops, m, d_rank, pairs, s);
-      else if (cap <= 18) ag_ms_launch_pairs<18>(V, x_hops, m, d_rank, pairs, s);
+    } else {
+      rc = ag_zero_i32(m.deg, V, s);
+      if (rc) return rc;
+      AG_KERNEL("ag_ms_adjacency_kernel", ag_ms_adjacency_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, edges,
+                Eu, d_active, m.deg, m.adj);
+      AG_LAUNCH_CHECK();
+      if (cap <= 18) ag_ms_launch_pairs<18>(V, x_hops, m, d_rank, pairs, s);
       else if (cap <= 36) ag_ms_launch_pairs<36>(V, x_hops, m, d_rank, pairs, s);
       else if (cap <= 90) ag_ms_launch_pairs<90>(V, x_hops, m, d_rank, pairs, s);
       else ag_ms_launch_pairs<216>(V, x_hops, m, d_rank, pairs, s);
       AG_LAUNCH_CHECK();
-      slot_base += V * cap;
     }
-    if (l < max_level) {
-      AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F, m.topo.uniq, Eu, static_cast<int>(V), nxt);
-      AG_LAUNCH_CHECK();
-      int32_t* t = cur;
-      cur = nxt;
-      nxt = t;
-    }
+    slot_base += ag_ms_level_slots(l, x_hops);
   }
   const int64_t n = slot_base;
   rc = ag_sort_u64(m.temp, m.temp_bytes, m.pairs_a, m.pairs_b, n, 0, 64, s);
   if (rc) return rc;
-  AG_KERNEL("ag_ms_flag_unique_kernel", ag_ms_flag_unique_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s, m.pairs_b, n, m.offsets);
+  AG_KERNEL("ag_ms_flag_unique_kernel", ag_ms_flag_unique_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s, m.pairs_b,
+            n, m.offsets);
   AG_LAUNCH_CHECK();
   rc = ag_exclusive_scan_i64(m.temp, m.temp_bytes, m.offsets, m.offsets, n, s);
   if (rc) return rc;
@@ -488,11 +544,8 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
   return AG_OK;
 }
 
-extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
-                                  const uint8_t* d_active, int64_t num_edges, int32_t* d_out_src, int32_t* d_out_tgt,
-                                  void* d_ws, size_t ws_bytes, void* stream) {
-  (void)d_rank;
-  (void)d_active;
+extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, int64_t num_edges,
+                                  int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream) {
   int rc = ag_ms_check(R, levels, nlevels, x_hops);
   if (rc) return rc;
   if (num_edges <= 0) return AG_OK;
@@ -502,7 +555,8 @@ extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int
   AgMsWs m;
   ag_ms_carve(c, R, levels, nlevels, x_hops, &m);
   if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_fill: workspace too small");
-  AG_KERNEL("ag_ms_emit_kernel", ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_b, m.offsets, m.slots, num_edges, d_out_src, d_out_tgt);
+  AG_KERNEL("ag_ms_emit_kernel", ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_b,
+            m.offsets, m.slots, num_edges, d_out_src, d_out_tgt);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

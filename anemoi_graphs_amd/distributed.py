@@ -134,7 +134,6 @@ class ShardedGraphBuilder:
     def _build_single(self) -> HeteroData:
         """The plain plugin sequence the orchestrator runs (create.py:78-90 of the reference)."""
         from .edges import CutOffEdges, KNNEdges, MultiScaleEdges
-        from .edges.attributes import EdgeDirection, EdgeLength
         from .nodes import TriNodes
 
         graph = HeteroData()
@@ -146,11 +145,14 @@ class ShardedGraphBuilder:
             MultiScaleEdges("hidden", "hidden", self.x_hops),
             KNNEdges("hidden", "data", self.k),
         ]
-        for b in builders:
-            graph = b.update_graph(graph)
+        attrs = {
+            "edge_length": {"_target_": "anemoi.graphs.edges.attributes.EdgeLength", "norm": self.len_norm},
+            "edge_dirs": {"_target_": "anemoi.graphs.edges.attributes.EdgeDirection", "norm": self.dir_norm},
+        }
+        for b in builders:  # as the orchestrator does: edges first, then the attributes of the edge set
+            graph = b.update_graph(graph, attrs_config=None)
             if self.attributes:
-                graph[b.name]["edge_length"] = EdgeLength(norm=self.len_norm).compute(graph, b.name)
-                graph[b.name]["edge_dirs"] = EdgeDirection(norm=self.dir_norm).compute(graph, b.name)
+                graph = b.register_attributes(graph, attrs)
         return graph
 
     # ---------------------------------------------------------------------------------- sharded
@@ -166,7 +168,7 @@ class ShardedGraphBuilder:
         be, comm, r, W = self.backend, self.comm, self.rank, self.world
         dev = self.data_local.device
         graph = HeteroData()
-        _xyz, _faces, hidden, order, rank_map = be.icosphere(self.resolution)
+        _xyz, _faces, hidden, order, rank_map, level_edges = be.icosphere(self.resolution)
         hidden = hidden.to(dev)
         graph["hidden"].x = hidden
         graph["hidden"].node_type = "TriNodes"
@@ -223,7 +225,8 @@ class ShardedGraphBuilder:
         dec[1] += self.d_lo
 
         # ---- processor: replicated
-        proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map)
+        proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,
+                                   level_edges)
 
         # ---- gather
         graph["data"].x = comm.all_gather_rows(self.data_local)

@@ -30,7 +30,7 @@ class BaseEdgeAttribute(ABC, NormaliserMixin):
             values = values[:, None]
         return place(self.normalise(values.contiguous()))
 
-    def compute(self, graph: HeteroData, edges_name: tuple[str, str, str], *args, **kwargs) -> torch.Tensor:
+    def check_nodes(self, graph: HeteroData, edges_name: tuple[str, str, str]) -> None:
         source_name, _, target_name = edges_name
         assert (
             source_name in graph.node_types
@@ -38,8 +38,40 @@ class BaseEdgeAttribute(ABC, NormaliserMixin):
         assert (
             target_name in graph.node_types
         ), f"Node \"{target_name}\" not found in graph. Optional nodes are {', '.join(graph.node_types)}."
+
+    def compute(self, graph: HeteroData, edges_name: tuple[str, str, str], *args, **kwargs) -> torch.Tensor:
+        self.check_nodes(graph, edges_name)
+        source_name, _, target_name = edges_name
         values = self.get_raw_values(graph, source_name, target_name, *args, **kwargs)
         return self.post_process(values)
+
+
+def compute_fused(graph: HeteroData, edges_name: tuple[str, str, str], attributes: dict) -> dict:
+    """Evaluate several edge attributes of one edge set.  An EdgeLength and a rotated-or-not
+    EdgeDirection of the same edge set share one kernel launch (the endpoints are gathered once);
+    the results are identical to calling ``compute`` on each attribute."""
+    source_name, _, target_name = edges_name
+    lengths = [a for a in attributes.values() if type(a) is EdgeLength]
+    directions = [a for a in attributes.values() if type(a) is EdgeDirection]
+    raw_len = raw_dir = None
+    if lengths and directions and len({d.luse_rotated_features for d in directions}) == 1:
+        for a in attributes.values():
+            a.check_nodes(graph, edges_name)
+        edge_index = graph[edges_name].edge_index
+        raw_len, raw_dir = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index,
+                                          rotated=directions[0].luse_rotated_features)
+    out = {}
+    n_len, n_dir = len(lengths), len(directions)
+    for name, a in attributes.items():
+        if raw_len is not None and type(a) is EdgeLength:
+            n_len -= 1  # normalisation is in place: all but the last user work on a copy of the raw values
+            out[name] = a.post_process(raw_len.clone() if n_len else raw_len)
+        elif raw_dir is not None and type(a) is EdgeDirection:
+            n_dir -= 1
+            out[name] = a.post_process(raw_dir.clone() if n_dir else raw_dir)
+        else:
+            out[name] = a.compute(graph, edges_name)
+    return out
 
 
 class EdgeDirection(BaseEdgeAttribute):

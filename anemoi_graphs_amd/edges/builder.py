@@ -62,8 +62,11 @@ class BaseEdgeBuilder(ABC):
         return graph
 
     def register_attributes(self, graph: HeteroData, config: dict) -> HeteroData:
-        for attr_name, attr_config in config.items():
-            graph[self.name][attr_name] = instantiate(attr_config).compute(graph, self.name)
+        from .attributes import compute_fused
+
+        attributes = {attr_name: instantiate(attr_config) for attr_name, attr_config in config.items()}
+        for attr_name, values in compute_fused(graph, self.name, attributes).items():
+            graph[self.name][attr_name] = values
         return graph
 
     def update_graph(self, graph: HeteroData, attrs_config: dict | None = None) -> HeteroData:
@@ -185,7 +188,7 @@ class MultiScaleEdges(BaseEdgeBuilder):
             raise ValueError(f"Invalid node type {source_nodes.node_type}")
         mesh = source_nodes["_nx_graph"]
         resolutions = list(source_nodes["_resolutions"])
-        return ops.multiscale_edges(mesh.resolution, resolutions, self.x_hops, mesh.rank)
+        return ops.multiscale_edges(mesh.resolution, resolutions, self.x_hops, mesh.rank, mesh.level_edges)
 
     def update_graph(self, graph: HeteroData, attrs_config: dict | None = None) -> HeteroData:
         node_type = graph[self.source_name].node_type

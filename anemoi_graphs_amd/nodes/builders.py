@@ -74,10 +74,11 @@ class IcosahedralMesh:
     here the device-side description of the icosphere -- node<->vertex permutations -- instead of a
     networkx graph.  ``number_of_nodes`` and ``nodes`` keep the two accessors callers use."""
 
-    def __init__(self, resolution: int, order: torch.Tensor, rank: torch.Tensor):
+    def __init__(self, resolution: int, order: torch.Tensor, rank: torch.Tensor, level_edges: torch.Tensor):
         self.resolution = resolution
         self.order = order  # node -> vertex (int32, device)
         self.rank = rank    # vertex -> node (int32, device)
+        self.level_edges = level_edges  # unique mesh edges of every refinement level (int64 keys, device)
 
     def number_of_nodes(self) -> int:
         return int(self.order.numel())
@@ -115,7 +116,7 @@ class TriNodes(IcosahedralNodes):
 
     def create_nodes(self):
         resolution = max(self.resolutions)
-        _xyz, _faces, latlon, order, rank = ops.icosphere(resolution)
-        mesh = IcosahedralMesh(resolution, order, rank)
+        _xyz, _faces, latlon, order, rank, level_edges = ops.icosphere(resolution)
+        mesh = IcosahedralMesh(resolution, order, rank, level_edges)
         coords = latlon if settings.device_resident else latlon.cpu()
         return mesh, coords, order.cpu().tolist() if not settings.device_resident else order

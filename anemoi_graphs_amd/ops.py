@@ -180,29 +180,32 @@ def remap_ids_(values: torch.Tensor, id_map: torch.Tensor) -> torch.Tensor:
 
 
 def icosphere(resolution: int, device: torch.device | None = None):
-    """(xyz float64 [V,3], faces int32 [F,3], latlon float32 [V,2] in node order, order int32 [V], rank int32 [V])."""
+    """(xyz float64 [V,3], faces int32 [F,3], latlon float32 [V,2] in node order, order int32 [V],
+    rank int32 [V], level_edges int64 [E_all] = unique mesh edges of every level 0..resolution)."""
     lib = _lib.load()
     dev = device_of() if device is None else device
-    v, f = ctypes.c_int64(0), ctypes.c_int64(0)
-    _lib.check(lib.ag_icosphere_sizes(resolution, ctypes.byref(v), ctypes.byref(f)), "ag_icosphere_sizes")
-    nv, nf = v.value, f.value
+    v, f, e = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.ag_icosphere_sizes(resolution, ctypes.byref(v), ctypes.byref(f), ctypes.byref(e)),
+               "ag_icosphere_sizes")
+    nv, nf, ne = v.value, f.value, e.value
     with torch.cuda.device(dev):
         xyz = torch.empty((nv, 3), dtype=torch.float64, device=dev)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
         latlon = torch.empty((nv, 2), dtype=torch.float32, device=dev)
         order = torch.empty(nv, dtype=torch.int32, device=dev)
         rank = torch.empty(nv, dtype=torch.int32, device=dev)
+        level_edges = torch.empty(ne, dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_icosphere_workspace_bytes(resolution), dev)
         _lib.check(
-            lib.ag_icosphere(resolution, _ptr(xyz), _ptr(faces), _ptr(latlon), _ptr(order), _ptr(rank), _ptr(ws),
-                             ws.numel(), _stream(dev)),
+            lib.ag_icosphere(resolution, _ptr(xyz), _ptr(faces), _ptr(latlon), _ptr(order), _ptr(rank),
+                             _ptr(level_edges), _ptr(ws), ws.numel(), _stream(dev)),
             "ag_icosphere",
         )
-    return xyz, faces, latlon, order, rank
+    return xyz, faces, latlon, order, rank, level_edges
 
 
 def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: torch.Tensor,
-                     active: torch.Tensor | None = None) -> torch.Tensor:
+                     level_edges: torch.Tensor, active: torch.Tensor | None = None) -> torch.Tensor:
     """edge_index [2,E] int32 of the multi-scale icosahedral edges, sorted by (target, source)."""
     lib = _lib.load()
     dev = rank.device
@@ -212,16 +215,16 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
         count = torch.zeros((), dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_multiscale_workspace_bytes(max_resolution, len(levels), x_hops), dev)
         _lib.check(
-            lib.ag_multiscale_count(max_resolution, lv, len(levels), x_hops, _ptr(rank), _ptr(act), _ptr(count),
-                                    _ptr(ws), ws.numel(), _stream(dev)),
+            lib.ag_multiscale_count(max_resolution, lv, len(levels), x_hops, _ptr(rank), _ptr(act), _ptr(level_edges),
+                                    _ptr(count), _ptr(ws), ws.numel(), _stream(dev)),
             "ag_multiscale_count",
         )
         num_edges = int(count.item())
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
         if num_edges:
             _lib.check(
-                lib.ag_multiscale_fill(max_resolution, lv, len(levels), x_hops, _ptr(rank), _ptr(act), num_edges,
-                                       _ptr(edge_index[0]), _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
+                lib.ag_multiscale_fill(max_resolution, lv, len(levels), x_hops, num_edges, _ptr(edge_index[0]),
+                                       _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_multiscale_fill",
             )
     return edge_index

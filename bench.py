@@ -51,7 +51,7 @@ def algorithmic_bytes(kernel: str, sizes: dict) -> float:
     if kernel == "ag_radius_kernel":
         return 8.0 * nd + 8.0 * nh + 8.0 * sizes["e_enc"]
     if kernel == "ag_edge_attrs_kernel":
-        return 36.0 * sizes["e_total"] / 3.0  # three launches (one per edge set); average launch
+        return 36.0 * sizes["e_total"] / 3.0  # one fused launch per edge set (3 per build); average launch
     return 0.0
 
 

@@ -91,38 +91,43 @@ int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t n
  * Icosphere nodes.
  * Replaces trimesh.creation.icosphere(subdivisions=R, radius=1.0) + cartesian_to_latlon_rad +
  * get_coordinates_ordering (generate/tri_icosahedron.py:47-49,121-122; generate/transforms.py:
- * 50-52; generate/utils.py:30-32).  Sizes: V = 10*4^R + 2, F = 20*4^R.
- *   d_xyz      float64 [V,3]  unit vertices in trimesh vertex order (level-l vertices are a prefix)
- *   d_faces    int32   [F,3]  faces of level R
- *   d_latlon   float32 [V,2]  (lat, lon) of the vertices in NODE order: latitude descending,
- *                             ties longitude descending, remaining ties vertex id descending
- *                             (what generate/utils.py:30-32 yields with stable sorts)
- *   d_order    int32   [V]    node -> vertex  (the reference's `node_ordering`)
- *   d_rank     int32   [V]    vertex -> node  (inverse permutation)
+ * 50-52; generate/utils.py:30-32).  Sizes: V = 10*4^R + 2, F = 20*4^R, E_all = 10*(4^(R+1) - 1).
+ *   d_xyz         float64 [V,3]  unit vertices in trimesh vertex order (level-l vertices are a prefix)
+ *   d_faces       int32   [F,3]  faces of level R
+ *   d_latlon      float32 [V,2]  (lat, lon) of the vertices in NODE order: latitude descending,
+ *                                ties longitude descending, remaining ties vertex id descending
+ *                                (what generate/utils.py:30-32 yields with stable sorts)
+ *   d_order       int32   [V]    node -> vertex  (the reference's `node_ordering`)
+ *   d_rank        int32   [V]    vertex -> node  (inverse permutation)
+ *   d_level_edges uint64  [E_all] (nullable) the unique undirected mesh edges of every level 0..R as
+ *                                (max vertex << 32 | min vertex), level l at offset 10*(4^l - 1).  This
+ *                                is what the reference keeps in `_nx_graph` for MultiScaleEdges
+ *                                (nodes/builders/from_refined_icosahedron.py:50-55).
  */
 #define AG_ICO_MAX_LEVEL 11
-int ag_icosphere_sizes(int R, int64_t* V, int64_t* F);
+int ag_icosphere_sizes(int R, int64_t* V, int64_t* F, int64_t* E_all);
 size_t ag_icosphere_workspace_bytes(int R);
 int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_t* d_order, int32_t* d_rank,
-                 void* d_ws, size_t ws_bytes, void* stream);
+                 uint64_t* d_level_edges, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Multi-scale icosahedral edges.
  * Replaces tri_icosahedron.add_edges_to_nx_graph (generate/tri_icosahedron.py:165-188) and
- * nx.to_scipy_sparse_array (edges/builder.py:453): for every level in `levels` all ordered
- * pairs of distinct level-l vertices within x_hops mesh hops, in node numbering (d_rank of
- * ag_icosphere for R = max level), de-duplicated over levels.  Output is sorted by
- * (target, source).  Two calls: count -> *d_num_edges (int64, device), then fill.
- * d_active (nullable, uint8 [V]) restricts every level's mesh to edges whose two vertices are
- * active (generate/tri_icosahedron.py:214-215).
+ * nx.to_scipy_sparse_array (edges/builder.py:453): for every level in `levels` (host array) all
+ * ordered pairs of distinct level-l vertices within x_hops mesh hops, in node numbering (d_rank
+ * and d_level_edges of ag_icosphere for the same R), de-duplicated over levels.  Output is sorted
+ * by (target, source).  Two calls sharing one workspace: count -> *d_num_edges (int64, device),
+ * then fill.  d_active (nullable, uint8 [V]) restricts every level's mesh to edges whose two
+ * vertices are active (generate/tri_icosahedron.py:214-215); vertices with d_rank < 0 are not
+ * nodes of the graph and produce no edges.
  */
 #define AG_MULTISCALE_MAX_HOPS 8
 size_t ag_multiscale_workspace_bytes(int R, int nlevels, int x_hops);
 int ag_multiscale_count(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
-                        const uint8_t* d_active, int64_t* d_num_edges, void* d_ws, size_t ws_bytes, void* stream);
-int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
-                       const uint8_t* d_active, int64_t num_edges, int32_t* d_out_src, int32_t* d_out_tgt,
-                       void* d_ws, size_t ws_bytes, void* stream);
+                        const uint8_t* d_active, const uint64_t* d_level_edges, int64_t* d_num_edges, void* d_ws,
+                        size_t ws_bytes, void* stream);
+int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, int64_t num_edges, int32_t* d_out_src,
+                       int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Edge attributes.

@@ -20,7 +20,7 @@ def icosphere(resolution, device=None):
     rank = np.empty_like(order)
     rank[order] = np.arange(len(order))
     return (torch.from_numpy(v), torch.from_numpy(f.astype(np.int32)), torch.from_numpy(coords[order].copy()),
-            torch.from_numpy(order.astype(np.int32)), torch.from_numpy(rank.astype(np.int32)))
+            torch.from_numpy(order.astype(np.int32)), torch.from_numpy(rank.astype(np.int32)), None)
 
 
 def nn_maxdist(x):
@@ -37,7 +37,7 @@ def knn(src, tgt, k):
     return torch.from_numpy(e[0].reshape(len(_np(tgt)), k).copy())
 
 
-def multiscale_edges(max_resolution, levels, x_hops, rank, active=None):
+def multiscale_edges(max_resolution, levels, x_hops, rank, level_edges=None, active=None):
     rank = _np(rank)
     order = np.empty_like(rank)
     order[rank] = np.arange(len(rank))

@@ -38,9 +38,9 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"exceeds" in lib.ag_last_error()
     assert lib.ag_nn_maxdist(None, 1, None, None, 0, None) == -1
     assert lib.ag_normalise(None, 10, 9, 0, None, 0, None) == -1
-    v, f = ctypes.c_int64(), ctypes.c_int64()
-    assert lib.ag_icosphere_sizes(7, ctypes.byref(v), ctypes.byref(f)) == 0
-    assert (v.value, f.value) == (163842, 327680)
-    assert lib.ag_icosphere_sizes(12, ctypes.byref(v), ctypes.byref(f)) == -1
+    v, f, e = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert lib.ag_icosphere_sizes(7, ctypes.byref(v), ctypes.byref(f), ctypes.byref(e)) == 0
+    assert (v.value, f.value, e.value) == (163842, 327680, 10 * (4**8 - 1))
+    assert lib.ag_icosphere_sizes(12, ctypes.byref(v), ctypes.byref(f), ctypes.byref(e)) == -1
     with pytest.raises(_lib.LibraryError):
-        _lib.check(lib.ag_icosphere_sizes(-1, None, None), "ag_icosphere_sizes")
+        _lib.check(lib.ag_icosphere_sizes(-1, None, None, None), "ag_icosphere_sizes")

@@ -52,7 +52,7 @@ def _single(grid, resolution, factor):
     from tests import oracle_backend as ob
 
     data = grids.named(grid)
-    _, _, hidden, order, rank = ob.icosphere(resolution)
+    _, _, hidden, order, rank, _ = ob.icosphere(resolution)
     hidden_np = hidden.numpy()
     radius = rp.cutoff_radius(hidden_np, factor)
     enc = rp.canonical_sort(rp.radius_edges(data, hidden_np, radius))

@@ -23,7 +23,7 @@ DOC_MULTILEVEL_EDGES = {0: 60, 1: 300, 2: 1260, 3: 5100, 4: 20460, 5: 81900, 6: 
 
 @pytest.mark.parametrize("r", [0, 1, 2, 3, 5])
 def test_icosphere_matches_restatement(device, r):
-    xyz, faces, latlon, order, rank = [t.cpu().numpy() for t in ops.icosphere(r, device)]
+    xyz, faces, latlon, order, rank, level_edges = [t.cpu().numpy() for t in ops.icosphere(r, device)]
     v, f = ico.icosphere(r)
     assert xyz.shape == (DOC_NODES[r], 3) and faces.shape == (DOC_FACES[r], 3)
     assert np.array_equal(faces, f)
@@ -39,10 +39,17 @@ def test_icosphere_matches_restatement(device, r):
         assert np.array_equal(order, want_order)
     assert np.array_equal(rank[order], np.arange(len(order)))
     assert np.all(np.diff(got[:, 0]) <= 0)  # latitude descending
+    # per-level unique edges: level l at offset 10 * (4**l - 1), as (max << 32 | min) keys
+    for l in range(r + 1):
+        fl = ico.icosphere(l)[1]
+        want_e = np.unique(ico.face_edges(fl), axis=0)
+        keys = level_edges[10 * (4**l - 1): 10 * (4 ** (l + 1) - 1)]
+        got_e = np.unique(np.stack([keys & 0xFFFFFFFF, keys >> 32], axis=1), axis=0)
+        assert np.array_equal(got_e, want_e), l
 
 
 def test_icosphere_invariants_r7(device):
-    xyz, faces, latlon, order, rank = ops.icosphere(7, device)
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(7, device)
     xyz = xyz.cpu().numpy()
     faces = faces.cpu().numpy()
     V = 10 * 4**7 + 2
@@ -73,8 +80,8 @@ def _relabel(x_ref, edge_ref, x_mine):
 @pytest.mark.parametrize("r,hops", [(0, 1), (1, 1), (2, 1), (2, 2), (3, 1), (3, 3)])
 def test_multiscale_golden(device, golden, r, hops):
     g = golden("tri_multiscale")
-    xyz, faces, latlon, order, rank = ops.icosphere(r, device)
-    e = ops.multiscale_edges(r, list(range(r + 1)), hops, rank).cpu().numpy()
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(r, device)
+    e = ops.multiscale_edges(r, list(range(r + 1)), hops, rank, level_edges).cpu().numpy()
     want = _relabel(g[f"r{r}_x"], g[f"r{r}_h{hops}_edge_index"], latlon.cpu().numpy())
     assert np.array_equal(e, h.canonical(want))
     if hops == 1:
@@ -83,28 +90,29 @@ def test_multiscale_golden(device, golden, r, hops):
 
 def test_multiscale_level_subset_golden(device, golden):
     g = golden("tri_multiscale")
-    xyz, faces, latlon, order, rank = ops.icosphere(3, device)
-    e = ops.multiscale_edges(3, [0, 2, 3], 1, rank).cpu().numpy()
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(3, device)
+    e = ops.multiscale_edges(3, [0, 2, 3], 1, rank, level_edges).cpu().numpy()
     want = _relabel(g["r023_x"], g["r023_h1_edge_index"], latlon.cpu().numpy())
     assert np.array_equal(e, h.canonical(want))
 
 
 @pytest.mark.parametrize("r,hops", [(4, 1), (4, 2), (3, 4)])
 def test_multiscale_live_oracle(device, r, hops):
-    xyz, faces, latlon, order, rank = ops.icosphere(r, device)
-    e = ops.multiscale_edges(r, list(range(r + 1)), hops, rank).cpu().numpy()
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(r, device)
+    e = ops.multiscale_edges(r, list(range(r + 1)), hops, rank, level_edges).cpu().numpy()
     want = rp.multiscale_edges(list(range(r + 1)), hops, order.cpu().numpy())
     assert np.array_equal(e, h.canonical(want))
 
 
 def test_multiscale_counts_and_symmetry_r7(device):
-    xyz, faces, latlon, order, rank = ops.icosphere(7, device)
-    e = ops.multiscale_edges(7, list(range(8)), 1, rank).cpu().numpy()
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(7, device)
+    e = ops.multiscale_edges(7, list(range(8)), 1, rank, level_edges).cpu().numpy()
     assert e.shape == (2, 20 * (4**8 - 1))  # 1,310,700
     assert (e[0] != e[1]).all()
     assert np.array_equal(e, h.canonical(e))
     assert np.array_equal(h.canonical(e[::-1]), e)  # symmetric edge set
-    e6 = ops.multiscale_edges(6, list(range(7)), 1, ops.icosphere(6, device)[4]).cpu().numpy()
+    ico6 = ops.icosphere(6, device)
+    e6 = ops.multiscale_edges(6, list(range(7)), 1, ico6[4], ico6[5]).cpu().numpy()
     assert e6.shape[1] == DOC_MULTILEVEL_EDGES[6]
 
 
@@ -114,8 +122,8 @@ def test_o96_tri5_documented_counts(device):
     from anemoi_graphs_amd import grids
 
     data = torch.from_numpy(grids.octahedral(96)).to(device)
-    xyz, faces, hidden, order, rank = ops.icosphere(5, device)
+    xyz, faces, hidden, order, rank, level_edges = ops.icosphere(5, device)
     radius = float(ops.nn_maxdist(hidden).item()) * 0.6
     assert ops.radius_edges(data, hidden, radius).shape[1] == 62980
-    assert ops.multiscale_edges(5, list(range(6)), 1, rank).shape[1] == 81900
+    assert ops.multiscale_edges(5, list(range(6)), 1, rank, level_edges).shape[1] == 81900
     assert ops.knn(hidden, data, 3).numel() == 120960

@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 name = sys.argv[1] if len(sys.argv) > 1 else "o1280"
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 data = torch.from_numpy(grids.named(name)).to(dev)
-_, _, hidden, order, rank = ops.icosphere(res, dev)
+_, _, hidden, order, rank, level_edges = ops.icosphere(res, dev)
 
 def timed(label, fn, n=5):
     fn(); torch.cuda.synchronize()
@@ -29,7 +29,7 @@ print("   knn stats (exact-path targets, extra rounds):", stats.tolist())
 timed("nn_maxdist hidden", lambda: ops.nn_maxdist(hidden))
 r = float(ops.nn_maxdist(hidden).item()) * 0.6
 enc = timed("radius enc", lambda: ops.radius_edges(data, hidden, r))
-proc = timed("multiscale", lambda: ops.multiscale_edges(res, list(range(res + 1)), 1, rank))
+proc = timed("multiscale", lambda: ops.multiscale_edges(res, list(range(res + 1)), 1, rank, level_edges))
 timed("icosphere", lambda: ops.icosphere(res, dev))
 dec = torch.stack([ids.reshape(-1), torch.arange(data.shape[0], dtype=torch.int32, device=dev).repeat_interleave(3)])
 timed("attrs dec", lambda: ops.edge_attrs(hidden, data, dec))
