@@ -20,6 +20,7 @@ SIGNATURES = {
     "ag_last_error": (c_char_p, []),
     "ag_version": (c_int, []),
     "ag_profile_enable": (c_int, [c_int]),
+    "ag_profile_filter": (c_int, [ctypes.c_char_p]),
     "ag_profile_collect": (c_int, [ctypes.c_char_p, c_size_t]),
     "ag_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),

@@ -1,8 +1,15 @@
 // Edge attributes (EdgeLength, EdgeDirection) and global normalisation for gfx950.
 //
-// One thread per edge: gather the two endpoints, evaluate the reference's formulas in the
-// reference's precisions, store.  The kernel is bound by the random 8-byte gathers (36 B of
-// compulsory traffic per edge) and by float64 arithmetic for the rotation.
+// The attribute kernel is bound by vector arithmetic (four float32 sin/cos evaluations, one
+// float64 arctangent and the float64 rotation per edge), not by its 20 B/edge of streamed
+// traffic plus the cached endpoint gathers, so the design removes work rather than bytes:
+//  * everything that depends on the target node only (its unit vector, the quaternion that takes
+//    it to the pole and the rotation matrix) is computed once per run of equal targets inside a
+//    block's chunk of edges and staged in LDS.  Edge lists from the builders are grouped by
+//    target, so a run is a target's whole row; an ungrouped list degrades to one run per edge,
+//    never to a wrong result;
+//  * float64 square roots and divisions use reciprocal (square root) seeds refined by two
+//    Newton steps, and the arctangent is a 17-term polynomial after one division.
 //
 // Precision contract
 //  * The reference evaluates cos/sin of float32 coordinates with numpy's float32 kernels.  numpy's
@@ -11,10 +18,16 @@
 //    and the same operation order, so the float32 unit vectors are bit-identical to numpy's on
 //    FMA-capable x86.  Arguments are latitudes/longitudes (|x| << 71476, the range of that path).
 //  * float32 products, sums and square roots are single IEEE operations (the library is built
-//    with -ffp-contract=off).  atan2 is evaluated in float64 and rounded once.
-//  * the rotation follows scipy's Rotation.from_rotvec(...).apply(...) in float64: unit
-//    quaternion -> matrix -> product (the quaternion is formed with half-angle identities).
+//    with -ffp-contract=off).
+//  * atan2 and the rotation (scipy's Rotation.from_rotvec(...).apply(...): unit quaternion ->
+//    matrix -> product) are evaluated in float64 to within a few float64 ulp (arctangent: 5e-15
+//    relative) and rounded to float32 once, so a stored value differs from the float32 rounding of
+//    the exact result in about one value per 10^7, by one float32 ulp.  The quaternion is formed
+//    with half-angle identities; normalisations of vectors that are unit by construction to
+//    within one float64 ulp are not repeated.
 #include "ag_common.hpp"
+
+#define AG_ATTR_CHUNK 512  // edges per block iteration (two per thread)
 
 __device__ __forceinline__ float ag_np_sin_f32(float x) {
   float s, c;
@@ -22,38 +35,77 @@ __device__ __forceinline__ float ag_np_sin_f32(float x) {
   return s;
 }
 
-// utils.haversine_distance (utils.py:99-103) in float32
-__device__ __forceinline__ float ag_edge_length(float2 sp, float2 tp) {
-  const float dlat = tp.x - sp.x;
-  const float dlon = tp.y - sp.y;
-  const float s0 = ag_np_sin_f32(dlat / 2.0f);
-  const float s1 = ag_np_sin_f32(dlon / 2.0f);
-  float ss, cs, st, ct;
-  ag_np_sincos_f32(sp.x, &ss, &cs);
+// 1/sqrt(x) for a normal, positive x: hardware seed (2^-23) + two Newton steps
+__device__ __forceinline__ double ag_rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = __builtin_fma(-(h * y), y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-(h * y), y, 0.5);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+
+// sqrt(x) for x >= 0 (normal or zero)
+__device__ __forceinline__ double ag_sqrt_f64(double x) { return x > 0.0 ? x * ag_rsqrt_f64(x) : 0.0; }
+
+// atan2(y, x) for y, x >= 0, not both zero; NaN if either is NaN.  atan(t) = t + t s Q(s), s = t^2,
+// on t = min/max in [0, 1]; Q interpolates (atan(t)/t - 1)/s at 17 Chebyshev nodes (tools/fit_atan.py).
+__device__ __forceinline__ double ag_atan2_pos(double y, double x) {
+  const double hi = fmax(x, y), lo = fmin(x, y);
+  double r = __builtin_amdgcn_rcp(hi);
+  double e = __builtin_fma(-hi, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-hi, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double t = lo * r;
+  t = __builtin_fma(__builtin_fma(-hi, t, lo), r, t);
+  const double s = t * t;
+  double p = -0x1.116cf4eed9ee2p-14;
+  p = __builtin_fma(p, s, 0x1.478bc19252cd1p-11);
+  p = __builtin_fma(p, s, -0x1.7239c656c970bp-9);
+  p = __builtin_fma(p, s, 0x1.090411c9f7d90p-7);
+  p = __builtin_fma(p, s, -0x1.11a34bdf175c0p-6);
+  p = __builtin_fma(p, s, 0x1.bb63244527d8fp-6);
+  p = __builtin_fma(p, s, -0x1.2e09b36d6dd7ep-5);
+  p = __builtin_fma(p, s, 0x1.705f0bf9c30f1p-5);
+  p = __builtin_fma(p, s, -0x1.a871f31487e16p-5);
+  p = __builtin_fma(p, s, 0x1.e0520791dacd2p-5);
+  p = __builtin_fma(p, s, -0x1.10ef041012eacp-4);
+  p = __builtin_fma(p, s, 0x1.3b0f9b9c5c124p-4);
+  p = __builtin_fma(p, s, -0x1.745cc3b58ce48p-4);
+  p = __builtin_fma(p, s, 0x1.c71c6db0fec78p-4);
+  p = __builtin_fma(p, s, -0x1.24924917024dcp-3);
+  p = __builtin_fma(p, s, 0x1.9999999975b97p-3);
+  p = __builtin_fma(p, s, -0x1.55555555554d6p-2);
+  const double at = __builtin_fma(t * s, p, t);
+  double res = (y > x) ? (AG_HALF_PI - at) : at;
+  if (x != x || y != y) res = x + y;
+  return res;
+}
+
+// Per-run (per distinct target) data staged in LDS
+struct AgAttrRuns {
+  double m00[AG_ATTR_CHUNK], m01[AG_ATTR_CHUNK], m02[AG_ATTR_CHUNK], m11[AG_ATTR_CHUNK], m12[AG_ATTR_CHUNK];
+  float lat[AG_ATTR_CHUNK], lon[AG_ATTR_CHUNK], cos_lat[AG_ATTR_CHUNK];
+  int tgt[AG_ATTR_CHUNK];
+  int seg[2 * 4 + 1];
+};
+
+// Target part of edges/directional.py:40-65 with generate/transforms.py:106-110,133-140: unit
+// vector of the target in float32, rotation taking it to the pole as a matrix in float64.
+__device__ __forceinline__ void ag_attr_target(float2 tp, bool rotated, AgAttrRuns& R, int r) {
+  float st, ct, so, co;
   ag_np_sincos_f32(tp.x, &st, &ct);
-  const float a = s0 * s0 + cs * ct * (s1 * s1);
-  const float y = sqrtf(a), x = sqrtf(1.0f - a);
-  return 2.0f * static_cast<float>(atan2(static_cast<double>(y), static_cast<double>(x)));
-}
-
-// generate/transforms.py:106-110 in float32
-__device__ __forceinline__ void ag_xyz_f32(float2 p, float* x, float* y, float* z) {
-  float sl, cl, so, co;
-  ag_np_sincos_f32(p.x, &sl, &cl);
-  ag_np_sincos_f32(p.y, &so, &co);
-  *x = cl * co;
-  *y = cl * so;
-  *z = sl;
-}
-
-// edges/directional.py:40-65 with generate/transforms.py:133-140
-__device__ __forceinline__ void ag_edge_direction(float2 sp, float2 tp, float* out_x, float* out_y) {
+  R.lat[r] = tp.x;
+  R.lon[r] = tp.y;
+  R.cos_lat[r] = ct;
+  if (!rotated) return;
+  ag_np_sincos_f32(tp.y, &so, &co);
+  float txf = ct * co, tyf = ct * so, tzf = st;
   const float eps32 = 10e-11f;
   const double eps = 10e-11;
-  float sxf, syf, szf, txf, tyf, tzf;
-  ag_xyz_f32(sp, &sxf, &syf, &szf);
-  ag_xyz_f32(tp, &txf, &tyf, &tzf);
-  // rotation taking the target to the pole: axis = target x pole, angle = acos(target . pole)
+  // axis = target x pole, angle = acos(target . pole)
   double vx = static_cast<double>(tyf), vy = -static_cast<double>(txf);
   double n2 = vx * vx + vy * vy;
   if (n2 < eps) {  // target at a pole: the reference nudges the float32 point in place
@@ -68,38 +120,60 @@ __device__ __forceinline__ void ag_edge_direction(float2 sp, float2 tp, float* o
   // axis * theta with theta = acos(z).  Since cos(theta) = z by definition, the half-angle identities
   // give the same quaternion without inverse trigonometry: sin(theta/2) = sqrt((1-z)/2),
   // cos(theta/2) = sqrt((1+z)/2); 1 -/+ z are exact in float64 for a float32 z.
-  const double norm_v = sqrt(n2);
+  const double inv_norm = ag_rsqrt_f64(n2);
   const double z = static_cast<double>(tzf);
-  const double sh = sqrt(0.5 * (1.0 - z)), ch = sqrt(0.5 * (1.0 + z));
-  double qx = (vx / norm_v) * sh, qy = (vy / norm_v) * sh, qz = 0.0, qw = ch;
-  const double qn = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
-  qx /= qn;
-  qy /= qn;
-  qw /= qn;
-  // scipy Rotation.as_matrix / apply
-  const double x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, w2 = qw * qw;
-  const double xy = qx * qy, zw = qz * qw, xz = qx * qz, yw = qy * qw, yz = qy * qz, xw = qx * qw;
-  const double m00 = x2 - y2 - z2 + w2, m01 = 2.0 * (xy - zw), m02 = 2.0 * (xz + yw);
-  const double m10 = 2.0 * (xy + zw), m11 = -x2 + y2 - z2 + w2, m12 = 2.0 * (yz - xw);
-  const double sx = sxf, sy = syf, sz = szf;
-  double px = m00 * sx + m01 * sy + m02 * sz;
-  double py = m10 * sx + m11 * sy + m12 * sz;
-  // direction of the rotated source with respect to the pole
-  double dx = py, dy = -px;
-  double m2 = dx * dx + dy * dy;
-  if (m2 < eps) {
-    px += eps;
-    py += eps;
-    dx = py;
-    dy = -px;
-    m2 = dx * dx + dy * dy;
+  const double sh = ag_sqrt_f64(0.5 * (1.0 - z)), ch = ag_sqrt_f64(0.5 * (1.0 + z));
+  const double qx = (vx * inv_norm) * sh, qy = (vy * inv_norm) * sh, qw = ch;  // qz = 0
+  // scipy Rotation.as_matrix, rows 0 and 1, with qz = 0 (m10 = m01)
+  const double x2 = qx * qx, y2 = qy * qy, w2 = qw * qw;
+  R.m00[r] = x2 - y2 + w2;
+  R.m01[r] = 2.0 * (qx * qy);
+  R.m02[r] = 2.0 * (qy * qw);
+  R.m11[r] = -x2 + y2 + w2;
+  R.m12[r] = -2.0 * (qx * qw);
+}
+
+// One edge: utils.haversine_distance (utils.py:99-103) in float32 and the direction of the
+// rotated source with respect to the pole (edges/directional.py:68-94).
+__device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int r, bool rotated, bool want_len,
+                                             bool want_dir, float* len, float2* dir) {
+  const float tlat = R.lat[r], tlon = R.lon[r];
+  float ss, cs;
+  ag_np_sincos_f32(sp.x, &ss, &cs);
+  if (want_len) {
+    const float ct = R.cos_lat[r];
+    const float dlat = tlat - sp.x;
+    const float dlon = tlon - sp.y;
+    const float s0 = ag_np_sin_f32(dlat / 2.0f);
+    const float s1 = ag_np_sin_f32(dlon / 2.0f);
+    const float a = s0 * s0 + cs * ct * (s1 * s1);
+    const float y = sqrtf(a), x = sqrtf(1.0f - a);
+    *len = 2.0f * static_cast<float>(ag_atan2_pos(static_cast<double>(y), static_cast<double>(x)));
   }
-  const double m = sqrt(m2);
-  dx /= m;
-  dy /= m;
-  const double renorm = sqrt(dx * dx + dy * dy);
-  *out_x = static_cast<float>(dx / renorm);
-  *out_y = static_cast<float>(dy / renorm);
+  if (want_dir) {
+    if (!rotated) {
+      *dir = make_float2(tlat - sp.x, tlon - sp.y);
+      return;
+    }
+    float so, co;
+    ag_np_sincos_f32(sp.y, &so, &co);
+    const double sx = static_cast<double>(cs * co), sy = static_cast<double>(cs * so), sz = static_cast<double>(ss);
+    const double m01 = R.m01[r];
+    double px = R.m00[r] * sx + m01 * sy + R.m02[r] * sz;
+    double py = m01 * sx + R.m11[r] * sy + R.m12[r] * sz;
+    const double eps = 10e-11;
+    double dx = py, dy = -px;
+    double m2 = dx * dx + dy * dy;
+    if (m2 < eps) {
+      px += eps;
+      py += eps;
+      dx = py;
+      dy = -px;
+      m2 = dx * dx + dy * dy;
+    }
+    const double inv = ag_rsqrt_f64(m2);
+    *dir = make_float2(static_cast<float>(dx * inv), static_cast<float>(dy * inv));
+  }
 }
 
 __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __restrict__ src_x,
@@ -107,20 +181,57 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
                                                             const int32_t* __restrict__ es,
                                                             const int32_t* __restrict__ et, int64_t E, int flags,
                                                             float* __restrict__ out_len, float2* __restrict__ out_dir) {
-  for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < E; e += int64_t(gridDim.x) * blockDim.x) {
-    const float2 sp = src_x[es[e]];
-    const float2 tp = tgt_x[et[e]];
-    if (out_len != nullptr) out_len[e] = ag_edge_length(sp, tp);
-    if (out_dir != nullptr) {
-      float dx, dy;
-      if (flags & AG_ATTR_ROTATED) {
-        ag_edge_direction(sp, tp, &dx, &dy);
-      } else {
-        dx = tp.x - sp.x;
-        dy = tp.y - sp.y;
-      }
-      out_dir[e] = make_float2(dx, dy);
+  __shared__ AgAttrRuns R;
+  const bool rotated = (flags & AG_ATTR_ROTATED) != 0 && out_dir != nullptr;
+  const bool want_len = out_len != nullptr, want_dir = out_dir != nullptr;
+  const int tid = threadIdx.x, lane = ag_lane(), wave = tid >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int64_t nchunks = (E + AG_ATTR_CHUNK - 1) / AG_ATTR_CHUNK;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t base = chunk * AG_ATTR_CHUNK;
+    // thread t owns edges base + t and base + 256 + t; segment j*4 + wave holds 64 consecutive edges
+    int t_id[2], s_id[2], run[2];
+    bool valid[2], first[2];
+    unsigned long long bal[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t e = base + j * 256 + tid;
+      valid[j] = e < E;
+      t_id[j] = valid[j] ? et[e] : -1;
+      s_id[j] = valid[j] ? es[e] : 0;
+      const int prev = (valid[j] && e > base) ? et[e - 1] : -1;
+      first[j] = valid[j] && (e == base || prev != t_id[j]);
+      bal[j] = __ballot(first[j]);
+      if (lane == 0) R.seg[j * 4 + wave] = __popcll(bal[j]);
     }
+    __syncthreads();
+    int nruns = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int before = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = R.seg[q];
+        if (q < j * 4 + wave) before += c;
+        if (j == 0) nruns += c;
+      }
+      run[j] = before + __popcll(bal[j] & below) + (first[j] ? 1 : 0) - 1;
+      if (first[j]) R.tgt[run[j]] = t_id[j];
+    }
+    __syncthreads();
+    for (int r = tid; r < nruns; r += 256) ag_attr_target(tgt_x[R.tgt[r]], rotated, R, r);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (!valid[j]) continue;
+      const int64_t e = base + j * 256 + tid;
+      float len;
+      float2 dir;
+      ag_attr_edge(src_x[s_id[j]], R, run[j], rotated, want_len, want_dir, &len, &dir);
+      if (want_len) out_len[e] = len;
+      if (want_dir) out_dir[e] = dir;
+    }
+    __syncthreads();  // the staged runs are overwritten by the next chunk
   }
 }
 
@@ -130,7 +241,7 @@ extern "C" int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tg
   AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
   if (E == 0 || (d_len == nullptr && d_dir == nullptr)) return AG_OK;
   AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
-  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, 256, 1 << 20)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir));
+  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, AG_ATTR_CHUNK, 256 * 8)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir));
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

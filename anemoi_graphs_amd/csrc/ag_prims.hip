@@ -38,6 +38,8 @@ struct ProfRec {
 };
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
+bool g_prof_open = false;   // the last begin recorded a start event
+std::string g_prof_filter;  // empty: every kernel; otherwise only the kernel of this name
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 
@@ -56,6 +58,8 @@ hipEvent_t prof_event() {
 void ag_prof_begin(const char* name, hipStream_t stream) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lock(g_prof_mutex);
+  g_prof_open = g_prof_filter.empty() || g_prof_filter == name;
+  if (!g_prof_open) return;
   ProfRec r{name, prof_event(), prof_event()};
   if (r.start) (void)hipEventRecord(r.start, stream);
   g_prof_recs.push_back(r);
@@ -64,6 +68,8 @@ void ag_prof_begin(const char* name, hipStream_t stream) {
 void ag_prof_end(hipStream_t stream) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lock(g_prof_mutex);
+  if (!g_prof_open) return;
+  g_prof_open = false;
   if (!g_prof_recs.empty() && g_prof_recs.back().stop) (void)hipEventRecord(g_prof_recs.back().stop, stream);
 }
 
@@ -75,6 +81,12 @@ extern "C" int ag_profile_enable(int on) {
   }
   g_prof_recs.clear();
   g_prof_on = on != 0;
+  return AG_OK;
+}
+
+extern "C" int ag_profile_filter(const char* name) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  g_prof_filter = name ? name : "";
   return AG_OK;
 }
 

@@ -694,7 +694,7 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
 template <int CAP>
 static void ag_launch_stage1(const AgKnnArgs& a, int64_t tcells_ub, hipStream_t stream) {
   const int blocks = ag_blocks(tcells_ub, AG_WAVES_PER_BLOCK);
-  AG_KERNEL("ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
+  AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
   if constexpr (CAP <= 12) {
     AG_KERNEL("ag_knn_resolve_kernel", ag_knn_resolve_kernel<CAP>, dim3(ag_blocks(a.nt, 256, 8192)), dim3(256), stream, a);
   }

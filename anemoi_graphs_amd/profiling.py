@@ -6,8 +6,12 @@ import ctypes
 from . import _lib
 
 
-def enable(on: bool = True) -> None:
-    _lib.check(_lib.load().ag_profile_enable(int(on)), "ag_profile_enable")
+def enable(on: bool = True, only: str | None = None) -> None:
+    """Start (or stop) bracketing kernel launches with events; ``only`` restricts the events to
+    launches of one kernel name, which keeps the host cost out of a timed region."""
+    lib = _lib.load()
+    _lib.check(lib.ag_profile_filter(only.encode() if only else None), "ag_profile_filter")
+    _lib.check(lib.ag_profile_enable(int(on)), "ag_profile_enable")
 
 
 def collect() -> dict[str, tuple[int, float]]:

@@ -42,6 +42,7 @@ int ag_version(void);
  * <total_ms>\n", into buf (NUL-terminated, truncated to buf_bytes); returns the untruncated
  * length.  ag_profile_enable(0|1) also discards what was recorded so far. */
 int ag_profile_enable(int on);
+int ag_profile_filter(const char* kernel_name); /* NULL or "": every kernel; else only launches of that name */
 int ag_profile_collect(char* buf, size_t buf_bytes);
 
 /* ---------------------------------------------------------------------------------------
