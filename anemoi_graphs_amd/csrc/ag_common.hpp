@@ -228,6 +228,62 @@ __device__ __forceinline__ void ag_for_each_range(const AgGrid& g, const int* __
 
 __device__ __forceinline__ int ag_lane() { return threadIdx.x & 63; }
 
+// The same enumeration for a single target point, one run per lane: run j (two per covered band,
+// the second one empty unless the longitude window wraps) comes back in lane j - j0 as [first,
+// last).  All lanes compute the window; every lane then fetches its own band's cells, so the
+// dependent loads of all bands overlap.  Returns the total number of runs (wave-uniform).
+__device__ __forceinline__ int ag_lane_range(const AgGrid& g, const int* __restrict__ cell_start, double lat,
+                                             double lonw, double R, int j, int* first, int* last) {
+  const double pad = 1.0e-7 + 1.0e-6 * R;
+  const int b0 = ag_band_of(g, lat + R + pad), b1 = ag_band_of(g, lat - R - pad);
+  const double phit = fabs(lat);
+  bool full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
+  double lo = 0.0, hi = 0.0;
+  if (!full) {
+    const double q = sin(R) / cos(phit);
+    if (q >= 1.0) {
+      full = true;
+    } else {
+      const double delta = asin(q) * (1.0 + 1.0e-6) + pad;
+      lo = lonw - delta;
+      hi = lonw + delta;
+      if (hi - lo >= AG_TWO_PI) full = true;
+    }
+  }
+  const int nruns = 2 * (b1 - b0 + 1);
+  *first = 0;
+  *last = 0;
+  if (j < nruns) {
+    const int b = b0 + (j >> 1);
+    const bool second = (j & 1) != 0;
+    const int nc = g.ncols[b];
+    const int base = g.off[b];
+    const double w = nc * AG_INV_TWO_PI;
+    const long long ca = static_cast<long long>(floor(lo * w));
+    const long long cb = static_cast<long long>(floor(hi * w));
+    const long long len = cb - ca + 1;
+    int c_first = 0, c_last = 0;  // cell range [c_first, c_last) inside the band
+    if (full || nc == 1 || len >= nc) {
+      c_last = second ? 0 : nc;
+    } else {
+      int cam = static_cast<int>(ca % nc);
+      if (cam < 0) cam += nc;
+      const int end = cam + static_cast<int>(len);
+      if (!second) {
+        c_first = cam;
+        c_last = min(end, nc);
+      } else if (end > nc) {
+        c_last = end - nc;
+      }
+    }
+    if (c_last > c_first) {
+      *first = cell_start[base + c_first];
+      *last = cell_start[base + c_last];
+    }
+  }
+  return nruns;
+}
+
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------

@@ -86,20 +86,23 @@ __global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, in
     const float2 p = pts[i];
     const int c = ag_cell_of(g, static_cast<double>(p.x), static_cast<double>(p.y));
     cell_of[i] = c;
-    // neighbouring points usually share a cell: one atomic per distinct cell of the wave
+    // Neighbouring points usually share a cell.  A run = consecutive lanes with the same cell; the
+    // first lane of every run takes the run's slots with one atomic (all runs of the wave in the
+    // same instruction) and hands the base to the lanes behind it.  Lanes past the end of the
+    // array are the highest lanes of the last wave, so an active lane's predecessor is active.
     const int lane = ag_lane();
-    unsigned long long todo = __ballot(1);
-    int slot = 0;
-    while (todo) {
-      const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-      const int c0 = __shfl(c, leader, 64);
-      const unsigned long long same = __ballot(c == c0) & todo;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&count[c0], __popcll(same));
-      base = __shfl(base, leader, 64);
-      if (c == c0) slot = base + __popcll(same & ((1ull << lane) - 1ull));
-      todo &= ~same;
-    }
+    const int prev = __shfl_up(c, 1, 64);
+    const bool head = (lane == 0) || (prev != c);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long active = __ballot(1);
+    const int my_head = 63 - __clzll(static_cast<long long>(heads & (~0ull >> (63 - lane))));
+    const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
+    const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1)
+                              : (64 - __clzll(static_cast<long long>(active)));
+    int base = 0;
+    if (head) base = atomicAdd(&count[c], run_end - lane);
+    base = __shfl(base, my_head, 64);
+    const int slot = base + (lane - my_head);
     slot_of[i] = slot;
   }
 }
@@ -808,6 +811,8 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
 // radius query
 // ---------------------------------------------------------------------------------------------
 #define AG_ROW_LDS 1024  // row entries a wave can sort in LDS
+#define AG_STASH_MAX 256  // longest row the count pass keeps for the fill pass
+#define AG_STASH_BUDGET (int64_t(1) << 26)  // entries of the stash over all targets
 
 struct AgRadiusArgs {
   AgGrid grid;
@@ -822,81 +827,262 @@ struct AgRadiusArgs {
   int64_t* offsets;  // count pass: counts are written here; fill pass: exclusive offsets
   int32_t* out_src;
   int32_t* out_tgt;
+  int32_t* stash;    // [nt * stash_cap] sorted rows of at most stash_cap entries, written by the count pass
+  int stash_cap;
 };
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void ag_radius_kernel(AgRadiusArgs a) {
-  __shared__ __attribute__((aligned(16))) int row_all[FILL ? 4 : 1][FILL ? AG_ROW_LDS + 4 : 4];
+// rows the count pass can keep: as long as possible within a fixed budget of entries
+static int ag_radius_stash_cap(int64_t nt) {
+  const int64_t cap = (AG_STASH_BUDGET / (nt > 0 ? nt : 1)) & ~int64_t(15);
+  return static_cast<int>(cap > AG_STASH_MAX ? AG_STASH_MAX : (cap < 16 ? 0 : cap));
+}
+
+// Sources within the radius of target t, found by the whole wave: returns the count; when `row` is
+// not null the matching ids are also stored (unsorted) at row[0 .. min(count, row_cap)), and when
+// `spill` is not null ids go there instead (rows too long for LDS).
+__device__ __forceinline__ int64_t ag_radius_search(const AgRadiusArgs& a, int64_t t, int* row, int row_cap,
+                                                    int32_t* spill) {
+  const int lane = ag_lane();
+  const float2 tpf = a.tgt[t];
+  const double tlat = tpf.x, tlon = tpf.y;
+  const double tlonw = ag_wrap_lon(tlon);
+  const float3 tu = ag_unit_vec(tpf.x, tpf.y);
+  int64_t cnt = 0;
+  int nruns = 64;
+  for (int j0 = 0; j0 < nruns; j0 += 64) {
+    int first, last;
+    nruns = ag_lane_range(a.grid, a.sstart, tlat, tlonw, a.radius, j0 + lane, &first, &last);
+    // flatten the runs of this group: inclusive prefix sum of their lengths over the lanes
+    int incl = last - first;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    const int excl = incl - (last - first);
+    const int live = min(nruns - j0, 64);
+    for (int q0 = 0; q0 < total; q0 += 64) {
+      const int q = q0 + lane;
+      bool in = false;
+      int id = 0;
+      // run of candidate q (every lane takes part in the cross-lane reads, also past the end)
+      int r = 0;
+      for (int j = 0; j < live; ++j) r += (q >= __builtin_amdgcn_readlane(incl, j)) ? 1 : 0;
+      r = min(r, 63);
+      const int p = __shfl(first, r, 64) + (q - __shfl(excl, r, 64));
+      if (q < total) {
+        const float4 s = a.spts[p];
+        id = __float_as_int(s.w);
+        const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        in = d <= a.c_out;
+        if (in && d > a.c_in) {
+          const float2 sp = a.src[id];
+          in = ag_rdist(tlat, tlon, sp.x, sp.y) <= a.rthr;
+        }
+      }
+      const unsigned long long m = __ballot(in);
+      if (in) {
+        const int64_t o = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (spill != nullptr) spill[o] = id;
+        else if (row != nullptr && o < row_cap) row[o] = id;
+      }
+      cnt += __popcll(m);
+    }
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ void ag_wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Rank sort of the n <= AG_ROW_LDS distinct ids in `row` (LDS, room for n rounded up to 4) into out[0..n)
+__device__ __forceinline__ void ag_row_rank_sort(int* row, int n, int32_t* __restrict__ out) {
+  const int lane = ag_lane();
+  const int n4 = (n + 3) & ~3;
+  if (lane < n4 - n) row[n + lane] = 0x7fffffff;  // pad to a multiple of 4 with a value that ranks last
+  ag_wave_sync_lds();
+  const int4* row4 = reinterpret_cast<const int4*>(row);
+  for (int e0 = 0; e0 < n; e0 += 128) {
+    // two elements per lane share every broadcast read of four row entries
+    const int ea = e0 + lane, eb = e0 + 64 + lane;
+    const int va = ea < n ? row[ea] : 0x7fffffff, vb = eb < n ? row[eb] : 0x7fffffff;
+    int ra = 0, rb = 0;
+    for (int j = 0; j < n4 / 4; ++j) {
+      const int4 q = row4[j];
+      ra += (q.x < va) + (q.y < va) + (q.z < va) + (q.w < va);
+      rb += (q.x < vb) + (q.y < vb) + (q.z < vb) + (q.w < vb);
+    }
+    if (ea < n) out[ra] = va;
+    if (eb < n) out[rb] = vb;
+  }
+}
+
+#define AG_RADIUS_GROUP 64  // targets staged per block (a quarter per wave)
+#define AG_RADIUS_RUNS 8  // runs of binned sources a block-staged target can have (3 bands x 2 + spare)
+
+// Rank sort for rows of at most 64 entries: one element per lane
+__device__ __forceinline__ void ag_row_rank_sort64(int* row, int n, int32_t* __restrict__ out) {
+  const int lane = ag_lane();
+  const int n4 = (n + 3) & ~3;
+  if (lane < n4 - n) row[n + lane] = 0x7fffffff;
+  ag_wave_sync_lds();
+  const int4* row4 = reinterpret_cast<const int4*>(row);
+  const int v = lane < n ? row[lane] : 0x7fffffff;
+  int r = 0;
+  for (int j = 0; j < n4 / 4; ++j) {
+    const int4 q = row4[j];
+    r += (q.x < v) + (q.y < v) + (q.z < v) + (q.w < v);
+  }
+  if (lane < n) out[r] = v;
+}
+
+// Count pass.  A block takes AG_RADIUS_GROUP consecutive targets.  Phase A: one THREAD per target computes what
+// depends on the target only (float32 unit vector, the runs of binned sources its window covers)
+// into LDS, so the float64 window arithmetic is paid once per target, not once per wave
+// instruction.  Phase B: every wave walks through its quarter of the group; for each, the whole wave tests the
+// flattened candidate list, compacts the matching ids into its LDS row, and rows of at most
+// stash_cap entries are sorted and kept in the stash so that the fill pass does not search again.
+__global__ __launch_bounds__(256) void ag_radius_count_kernel(AgRadiusArgs a) {
+  __shared__ __attribute__((aligned(16))) int row_all[4][AG_STASH_MAX + 4];
+  __shared__ __attribute__((aligned(16))) int t_first[AG_RADIUS_GROUP][AG_RADIUS_RUNS];
+  __shared__ __attribute__((aligned(16))) int t_incl[AG_RADIUS_GROUP][AG_RADIUS_RUNS];
+  __shared__ float4 t_unit[AG_RADIUS_GROUP];  // w: 1 when the target needs the wave-level search (too many runs)
   const int lane = ag_lane();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int* row = row_all[FILL ? wave : 0];
+  int* row = row_all[wave];
+  for (int64_t t0 = int64_t(blockIdx.x) * AG_RADIUS_GROUP; t0 < a.nt; t0 += int64_t(gridDim.x) * AG_RADIUS_GROUP) {
+    {  // phase A
+      const int i = threadIdx.x;
+      const int64_t t = t0 + i;
+      if (i < AG_RADIUS_GROUP && t < a.nt) {
+        const float2 tpf = a.tgt[t];
+        const float3 tu = ag_unit_vec(tpf.x, tpf.y);
+        const double tlat = tpf.x, tlonw = ag_wrap_lon(static_cast<double>(tpf.y));
+        int run = 0, nruns = 1;
+        bool slow = false;
+        for (int j = 0; j < nruns; ++j) {
+          int first, last;
+          nruns = ag_lane_range(a.grid, a.sstart, tlat, tlonw, a.radius, j, &first, &last);
+          if (nruns > AG_RADIUS_RUNS) {
+            slow = true;
+            break;
+          }
+          run += last - first;
+          t_first[i][j] = first;
+          t_incl[i][j] = run;
+        }
+        for (int j = slow ? 0 : nruns; j < AG_RADIUS_RUNS; ++j) {
+          t_first[i][j] = 0;
+          t_incl[i][j] = slow ? 0 : run;
+        }
+        t_unit[i] = make_float4(tu.x, tu.y, tu.z, slow ? 1.0f : 0.0f);
+      }
+    }
+    __syncthreads();
+    // phase B
+    int my_count = 0;
+    constexpr int per_wave = AG_RADIUS_GROUP / 4;
+    const int i_end = static_cast<int>(min(int64_t(per_wave), a.nt - t0 - wave * per_wave));
+    for (int k = 0; k < i_end; ++k) {
+      const int i = wave * per_wave + k;
+      const int64_t t = t0 + i;
+      const float4 tu = t_unit[i];
+      int cnt = 0;
+      if (tu.w != 0.0f) {
+        cnt = static_cast<int>(min(ag_radius_search(a, t, a.stash_cap > 0 ? row : nullptr, a.stash_cap, nullptr),
+                                   int64_t(0x7fffffff)));
+      } else {
+        const int4 fa = *reinterpret_cast<const int4*>(&t_first[i][0]), fb = *reinterpret_cast<const int4*>(&t_first[i][4]);
+        const int4 ia = *reinterpret_cast<const int4*>(&t_incl[i][0]), ib = *reinterpret_cast<const int4*>(&t_incl[i][4]);
+        const int total = ib.w;
+        float2 tpf = make_float2(0.f, 0.f);
+        bool have_tp = false;
+        for (int q0 = 0; q0 < total; q0 += 64) {
+          const int q = q0 + lane;
+          bool in = false;
+          int id = 0;
+          if (q < total) {
+            // run of candidate q and its position in the binned array
+            int first = fa.x, excl = 0;
+            if (q >= ia.x) { first = fa.y; excl = ia.x; }
+            if (q >= ia.y) { first = fa.z; excl = ia.y; }
+            if (q >= ia.z) { first = fa.w; excl = ia.z; }
+            if (q >= ia.w) { first = fb.x; excl = ia.w; }
+            if (q >= ib.x) { first = fb.y; excl = ib.x; }
+            if (q >= ib.y) { first = fb.z; excl = ib.y; }
+            if (q >= ib.z) { first = fb.w; excl = ib.z; }
+            const float4 s = a.spts[first + (q - excl)];
+            id = __float_as_int(s.w);
+            const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            in = d <= a.c_out;
+            if (in && d > a.c_in) {
+              if (!have_tp) {
+                tpf = a.tgt[t];
+                have_tp = true;
+              }
+              const float2 sp = a.src[id];
+              in = ag_rdist(static_cast<double>(tpf.x), static_cast<double>(tpf.y), sp.x, sp.y) <= a.rthr;
+            }
+          }
+          const unsigned long long m = __ballot(in);
+          if (in) {
+            const int o = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (o < a.stash_cap) row[o] = id;
+          }
+          cnt += __popcll(m);
+        }
+      }
+      if (lane == k) my_count = cnt;
+      if (cnt > 0 && cnt <= a.stash_cap) {
+        ag_wave_sync_lds();
+        if (cnt <= 64) ag_row_rank_sort64(row, cnt, a.stash + t * a.stash_cap);
+        else ag_row_rank_sort(row, cnt, a.stash + t * a.stash_cap);
+      }
+      ag_wave_sync_lds();  // the row is reused by the next target
+    }
+    if (lane < i_end) a.offsets[t0 + wave * per_wave + lane] = my_count;
+    __syncthreads();  // the staged targets are overwritten by the next group
+  }
+}
+
+// Fill pass: rows kept by the count pass are copied; longer rows are searched again, sorted in LDS
+// (up to AG_ROW_LDS entries) or in place in global memory.
+__global__ __launch_bounds__(256) void ag_radius_fill_kernel(AgRadiusArgs a) {
+  __shared__ __attribute__((aligned(16))) int row_all[4][AG_ROW_LDS + 4];
+  const int lane = ag_lane();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int* row = row_all[wave];
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
   for (int64_t t = wave_global; t < a.nt; t += nwaves) {
-    const float2 tpf = a.tgt[t];
-    const double tlat = tpf.x, tlon = tpf.y;
-    const double tlonw = ag_wrap_lon(tlon);
-    const float3 tu = ag_unit_vec(tpf.x, tpf.y);
-    int64_t cnt = 0;
-    const int64_t base_out = FILL ? a.offsets[t] : 0;
-    const int64_t n_row = FILL ? a.offsets[t + 1] - base_out : 0;
-    const bool in_lds = FILL && n_row <= AG_ROW_LDS;
-    ag_for_each_range(a.grid, a.sstart, tlat, tlat, tlonw, tlonw, a.radius, [&](int first, int last) {
-      for (int p0 = first; p0 < last; p0 += 64) {
-        const int p = p0 + lane;
-        bool in = false;
-        int id = 0;
-        if (p < last) {
-          const float4 s = a.spts[p];
-          id = __float_as_int(s.w);
-          const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
-          const float d = dx * dx + dy * dy + dz * dz;
-          in = d <= a.c_out;
-          if (in && d > a.c_in) {
-            const float2 sp = a.src[id];
-            in = ag_rdist(tlat, tlon, sp.x, sp.y) <= a.rthr;
-          }
-        }
-        const unsigned long long m = __ballot(in);
-        if (FILL && in) {
-          const int64_t o = cnt + __popcll(m & ((1ull << lane) - 1ull));
-          if (in_lds) row[o] = id;
-          else a.out_tgt[base_out + o] = id;  // the target column doubles as scratch for long rows
-        }
-        cnt += __popcll(m);
+    const int64_t base_out = a.offsets[t];
+    const int64_t n_row = a.offsets[t + 1] - base_out;
+    if (n_row <= a.stash_cap) {
+      const int32_t* kept = a.stash + t * a.stash_cap;
+      for (int e = lane; e < n_row; e += 64) {
+        a.out_src[base_out + e] = kept[e];
+        a.out_tgt[base_out + e] = static_cast<int32_t>(t);
       }
-    });
-    if (!FILL) {
-      if (lane == 0) a.offsets[t] = cnt;
       continue;
     }
-    // rank sort: source ids are distinct inside a row, so rank = number of smaller ids
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (in_lds) {
-      const int n = static_cast<int>(n_row);
-      const int n4 = (n + 3) & ~3;
-      if (lane < n4 - n) row[n + lane] = 0x7fffffff;  // pad to a multiple of 4 with a value that ranks last
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int4* row4 = reinterpret_cast<const int4*>(row);
-      for (int e0 = 0; e0 < n; e0 += 128) {
-        // two elements per lane share every broadcast read of four row entries
-        const int ea = e0 + lane, eb = e0 + 64 + lane;
-        const int va = ea < n ? row[ea] : 0x7fffffff, vb = eb < n ? row[eb] : 0x7fffffff;
-        int ra = 0, rb = 0;
-        for (int j = 0; j < n4 / 4; ++j) {
-          const int4 q = row4[j];
-          ra += (q.x < va) + (q.y < va) + (q.z < va) + (q.w < va);
-          rb += (q.x < vb) + (q.y < vb) + (q.z < vb) + (q.w < vb);
-        }
-        if (ea < n) a.out_src[base_out + ra] = va;
-        if (eb < n) a.out_src[base_out + rb] = vb;
-      }
-      for (int e = lane; e < n; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
+    if (n_row <= AG_ROW_LDS) {
+      (void)ag_radius_search(a, t, row, AG_ROW_LDS, nullptr);
+      ag_wave_sync_lds();
+      ag_row_rank_sort(row, static_cast<int>(n_row), a.out_src + base_out);
+      for (int e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
+      ag_wave_sync_lds();
     } else {
+      // the target column doubles as scratch for long rows; source ids are distinct inside a
+      // row, so rank = number of smaller ids
+      (void)ag_radius_search(a, t, nullptr, 0, a.out_tgt + base_out);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       for (int64_t e = lane; e < n_row; e += 64) {
         const int mine = a.out_tgt[base_out + e];
         int64_t rank = 0;
@@ -907,8 +1093,6 @@ __global__ __launch_bounds__(256) void ag_radius_kernel(AgRadiusArgs a) {
       __builtin_amdgcn_wave_barrier();
       for (int64_t e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -916,13 +1100,16 @@ struct AgRadiusWs {
   AgBinned src;
   void* scan_temp;
   size_t scan_temp_bytes;
+  int32_t* stash;
+  int stash_cap;
 };
 
 // cell size for a radius query: the query radius itself, but never so small that the grid has
 // many more cells than there are sources
 static double ag_radius_delta(int64_t ns, double radius) {
   const double spacing = sqrt(4.0 * AG_PI / static_cast<double>(ns));
-  double d = radius > spacing ? radius : spacing;
+  const double r = radius * 1.001 + 4.0e-7;  // > radius + pad: a window never spans more than 3 bands
+  double d = r > spacing ? r : spacing;
   if (d > AG_PI) d = AG_PI;
   return d;
 }
@@ -946,9 +1133,13 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
   }
   const size_t stb = ag_scan_i64_temp_bytes(nt);
   void* st = c.take<char>(stb);
+  const int cap = ag_radius_stash_cap(nt);
+  int32_t* stash = c.take<int32_t>(nt * cap + 4);
   if (w) {
     w->scan_temp = st;
     w->scan_temp_bytes = stb;
+    w->stash = stash;
+    w->stash_cap = cap;
   }
   return AG_OK;
 }
@@ -968,6 +1159,8 @@ static int ag_radius_args(const float* d_src, const float* d_tgt, int64_t nt, do
   a->src = reinterpret_cast<const float2*>(d_src);
   a->tgt = reinterpret_cast<const float2*>(d_tgt);
   a->nt = nt;
+  a->stash = w.stash;
+  a->stash_cap = w.stash_cap;
   a->radius = radius < AG_PI ? radius : AG_PI;
   const double s = sin(0.5 * radius);
   a->rthr = s * s;
@@ -1002,7 +1195,7 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
   a.out_src = nullptr;
   a.out_tgt = nullptr;
   if (nt > 0) {
-    AG_KERNEL("ag_radius_kernel_count", ag_radius_kernel<false>, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
+    AG_KERNEL("ag_radius_count_kernel", ag_radius_count_kernel, dim3(ag_blocks(nt, AG_RADIUS_GROUP, 65536)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
   return ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
@@ -1025,7 +1218,7 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
   a.offsets = const_cast<int64_t*>(d_offsets);
   a.out_src = d_out_src;
   a.out_tgt = d_out_tgt;
-  AG_KERNEL("ag_radius_kernel_fill", ag_radius_kernel<true>, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
+  AG_KERNEL("ag_radius_fill_kernel", ag_radius_fill_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -51,8 +51,8 @@ def algorithmic_bytes(kernel: str, sizes: dict) -> float:
         return 8.0 * nh + 8.0 * nd + 4.0 * KNN_K * nd
     if kernel == "ag_knn_cell_kernel_self":  # reference distance: hidden -> hidden, one distance per node
         return 8.0 * nh + 8.0 * nh + 8.0 * nh
-    if kernel in ("ag_radius_kernel_count", "ag_radius_kernel_fill"):
-        out = 8.0 * sizes["e_enc"] if kernel.endswith("fill") else 8.0 * nh
+    if kernel in ("ag_radius_count_kernel", "ag_radius_fill_kernel"):
+        out = 8.0 * sizes["e_enc"] if "fill" in kernel else 8.0 * nh
         return 8.0 * nd + 8.0 * nh + out
     if kernel == "ag_edge_attrs_kernel":
         # one fused launch per edge set (3 per build), averaged: ids read + attributes written per
