@@ -113,12 +113,58 @@ __device__ __forceinline__ int ag_cell_of(const AgGrid& g, double lat, double lo
   return g.off[b] + c;
 }
 
+// float64 sine and cosine for coordinate-sized arguments (|x| < 1e6 rad; latitudes, longitudes and
+// their half differences), < 1 ulp: two-constant Cody-Waite reduction by pi/2 with fused
+// multiply-adds, then the fdlibm kernels (__kernel_sin / __kernel_cos, 13th / 14th degree) on
+// [-pi/4, pi/4] with the reduction's tail.  Unlike the general library routines there is no
+// large-argument path, which keeps the register footprint of the calling kernels small.
+__device__ __forceinline__ void ag_sincos_f64(double x, double* s_out, double* c_out) {
+  const double k = rint(x * 0x1.45f306dc9c883p-1);  // x * 2/pi
+  const double r0 = __builtin_fma(-k, 0x1.921fb54442d18p+0, x);
+  const double r = __builtin_fma(-k, 0x1.1a62633145c07p-54, r0);
+  const double tail = __builtin_fma(-k, 0x1.1a62633145c07p-54, r0 - r);  // (r0 - r) - k*P2
+  const double z = r * r;
+  // sine kernel
+  const double v = z * r;
+  double ps = __builtin_fma(z, 0x1.5d93a5acfd57cp-33, -0x1.ae5e68a2b9cebp-26);
+  ps = __builtin_fma(z, ps, 0x1.71de357b1fe7dp-19);
+  ps = __builtin_fma(z, ps, -0x1.a01a019c161d5p-13);
+  ps = __builtin_fma(z, ps, 0x1.111111110f8a6p-7);
+  const double sn = r - ((z * (0.5 * tail - v * ps) - tail) - v * -0x1.5555555555549p-3);
+  // cosine kernel
+  double pc = __builtin_fma(z, -0x1.8fae9be8838d4p-37, 0x1.1ee9ebdb4b1c4p-29);
+  pc = __builtin_fma(z, pc, -0x1.27e4f809c52adp-22);
+  pc = __builtin_fma(z, pc, 0x1.a01a019cb159p-16);
+  pc = __builtin_fma(z, pc, -0x1.6c16c16c15177p-10);
+  pc = __builtin_fma(z, pc, 0x1.555555555554cp-5);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + (z * (z * pc) - r * tail));
+  const int q = static_cast<int>(k) & 3;
+  const double s = (q & 1) ? cs : sn;
+  const double c = (q & 1) ? sn : cs;
+  *s_out = (q & 2) ? -s : s;
+  *c_out = ((q + 1) & 2) ? -c : c;
+}
+
+__device__ __forceinline__ double ag_sin_f64(double x) {
+  double s, c;
+  ag_sincos_f64(x, &s, &c);
+  return s;
+}
+
+__device__ __forceinline__ double ag_cos_f64(double x) {
+  double s, c;
+  ag_sincos_f64(x, &s, &c);
+  return c;
+}
+
 // The float64 "reduced distance" scikit-learn ranks by (sklearn/metrics/_dist_metrics.pyx.tp,
 // HaversineDistance.rdist): separate roundings, no fused multiply-add (built with -ffp-contract=off).
 __device__ __forceinline__ double ag_rdist(double lat1, double lon1, double lat2, double lon2) {
-  const double s0 = sin(0.5 * (lat1 - lat2));
-  const double s1 = sin(0.5 * (lon1 - lon2));
-  return (s0 * s0 + cos(lat1) * cos(lat2) * s1 * s1);
+  const double s0 = ag_sin_f64(0.5 * (lat1 - lat2));
+  const double s1 = ag_sin_f64(0.5 * (lon1 - lon2));
+  return (s0 * s0 + ag_cos_f64(lat1) * ag_cos_f64(lat2) * s1 * s1);
 }
 
 __device__ __forceinline__ double ag_rdist_to_dist(double r) { return 2.0 * asin(sqrt(r)); }
@@ -166,8 +212,8 @@ __device__ __forceinline__ float3 ag_unit_vec_f32(float lat, float lon) {
 // float32 unit vector of a (lat, lon) point, rounded from float64
 __device__ __forceinline__ float3 ag_unit_vec(float lat, float lon) {
   double sl, cl, so, co;
-  sincos(static_cast<double>(lat), &sl, &cl);
-  sincos(static_cast<double>(lon), &so, &co);
+  ag_sincos_f64(static_cast<double>(lat), &sl, &cl);
+  ag_sincos_f64(static_cast<double>(lon), &so, &co);
   return make_float3(static_cast<float>(cl * co), static_cast<float>(cl * so), static_cast<float>(sl));
 }
 
@@ -190,7 +236,7 @@ __device__ __forceinline__ void ag_for_each_range(const AgGrid& g, const int* __
   bool full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
   double lo = 0.0, hi = 0.0;
   if (!full) {
-    const double q = sin(R) / cos(phit);
+    const double q = ag_sin_f64(R) / ag_cos_f64(phit);
     if (q >= 1.0) {
       full = true;
     } else {
@@ -240,7 +286,7 @@ __device__ __forceinline__ int ag_lane_range(const AgGrid& g, const int* __restr
   bool full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
   double lo = 0.0, hi = 0.0;
   if (!full) {
-    const double q = sin(R) / cos(phit);
+    const double q = ag_sin_f64(R) / ag_cos_f64(phit);
     if (q >= 1.0) {
       full = true;
     } else {

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
   for (int b = b_begin; b < b_end; ++b) {
     const double lat_hi = AG_HALF_PI - b * dlat, lat_lo = lat_hi - dlat;
     const double mid = AG_HALF_PI - (b + 0.5) * dlat;
-    int nc = static_cast<int>(floor(AG_TWO_PI * cos(mid) / dlat));
+    int nc = static_cast<int>(floor(AG_TWO_PI * ag_cos_f64(mid) / dlat));
     nc = max(nc, 1) * mult;
     ncols[b] = nc;
     sum += nc;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
     const double phit = fmax(fabs(lat_lo), fabs(lat_hi));
     double w = -1.0;
     if (phit + rg + pad < AG_HALF_PI && rg < AG_HALF_PI) {
-      const double q = sin(rg) / cos(phit);
+      const double q = ag_sin_f64(rg) / ag_cos_f64(phit);
       if (q < 1.0) w = asin(q) * (1.0 + 1.0e-6) + pad;
     }
     win[b] = w;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
     for (;;) {
       const bool whole = R >= AG_PI;
       const double Rw = whole ? AG_PI : R;
-      const double s = sin(0.5 * Rw);
+      const double s = ag_sin_f64(0.5 * Rw);
       const double rlimit = s * s * (1.0 - 1.0e-9);
       double prev_r = -1.0;
       int prev_i = -1;
@@ -813,6 +813,14 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
 #define AG_ROW_LDS 1024  // row entries a wave can sort in LDS
 #define AG_STASH_MAX 256  // longest row the count pass keeps for the fill pass
 #define AG_STASH_BUDGET (int64_t(1) << 26)  // entries of the stash over all targets
+#define AG_RADIUS_RUNS 8  // runs of binned sources in a target's window (3 bands x 2 + spare)
+
+// What the search needs to know about a target, computed once per target by one thread
+struct __attribute__((aligned(16))) AgRadiusDesc {
+  int first[AG_RADIUS_RUNS];  // start of every run in the binned source array
+  int incl[AG_RADIUS_RUNS];   // inclusive prefix sum of the run lengths; incl[last] = candidates
+  float4 unit;                // float32 unit vector of the target (rounded from float64)
+};
 
 struct AgRadiusArgs {
   AgGrid grid;
@@ -829,6 +837,7 @@ struct AgRadiusArgs {
   int32_t* out_tgt;
   int32_t* stash;    // [nt * stash_cap] sorted rows of at most stash_cap entries, written by the count pass
   int stash_cap;
+  AgRadiusDesc* desc;  // [nt]
 };
 
 // rows the count pass can keep: as long as possible within a fixed budget of entries
@@ -837,67 +846,105 @@ static int ag_radius_stash_cap(int64_t nt) {
   return static_cast<int>(cap > AG_STASH_MAX ? AG_STASH_MAX : (cap < 16 ? 0 : cap));
 }
 
-// Sources within the radius of target t, found by the whole wave: returns the count; when `row` is
-// not null the matching ids are also stored (unsorted) at row[0 .. min(count, row_cap)), and when
-// `spill` is not null ids go there instead (rows too long for LDS).
-__device__ __forceinline__ int64_t ag_radius_search(const AgRadiusArgs& a, int64_t t, int* row, int row_cap,
-                                                    int32_t* spill) {
-  const int lane = ag_lane();
-  const float2 tpf = a.tgt[t];
-  const double tlat = tpf.x, tlon = tpf.y;
-  const double tlonw = ag_wrap_lon(tlon);
-  const float3 tu = ag_unit_vec(tpf.x, tpf.y);
-  int64_t cnt = 0;
-  int nruns = 64;
-  for (int j0 = 0; j0 < nruns; j0 += 64) {
-    int first, last;
-    nruns = ag_lane_range(a.grid, a.sstart, tlat, tlonw, a.radius, j0 + lane, &first, &last);
-    // flatten the runs of this group: inclusive prefix sum of their lengths over the lanes
-    int incl = last - first;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += v;
-    }
-    const int total = __shfl(incl, 63, 64);
-    const int excl = incl - (last - first);
-    const int live = min(nruns - j0, 64);
-    for (int q0 = 0; q0 < total; q0 += 64) {
-      const int q = q0 + lane;
-      bool in = false;
-      int id = 0;
-      // run of candidate q (every lane takes part in the cross-lane reads, also past the end)
-      int r = 0;
-      for (int j = 0; j < live; ++j) r += (q >= __builtin_amdgcn_readlane(incl, j)) ? 1 : 0;
-      r = min(r, 63);
-      const int p = __shfl(first, r, 64) + (q - __shfl(excl, r, 64));
-      if (q < total) {
-        const float4 s = a.spts[p];
-        id = __float_as_int(s.w);
-        const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
-        const float d = dx * dx + dy * dy + dz * dz;
-        in = d <= a.c_out;
-        if (in && d > a.c_in) {
-          const float2 sp = a.src[id];
-          in = ag_rdist(tlat, tlon, sp.x, sp.y) <= a.rthr;
-        }
+// One thread per target: float32 unit vector and the runs of binned sources its window covers.
+// The float64 window arithmetic is paid once per target here, not once per wave instruction in
+// the search.
+__global__ __launch_bounds__(256) void ag_radius_window_kernel(AgRadiusArgs a) {
+  for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < a.nt; t += int64_t(gridDim.x) * blockDim.x) {
+    const float2 tpf = a.tgt[t];
+    const float3 tu = ag_unit_vec(tpf.x, tpf.y);
+    const double tlat = tpf.x, tlonw = ag_wrap_lon(static_cast<double>(tpf.y));
+    AgRadiusDesc d;
+    int run = 0, nruns = 1;
+    bool merged = false;
+    for (int j = 0; j < nruns; ++j) {
+      int first, last;
+      nruns = ag_lane_range(a.grid, a.sstart, tlat, tlonw, a.radius, j, &first, &last);
+      if (nruns > AG_RADIUS_RUNS) {
+        merged = true;
+        break;
       }
-      const unsigned long long m = __ballot(in);
-      if (in) {
-        const int64_t o = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (spill != nullptr) spill[o] = id;
-        else if (row != nullptr && o < row_cap) row[o] = id;
-      }
-      cnt += __popcll(m);
+      run += last - first;
+      d.first[j] = first;
+      d.incl[j] = run;
     }
+    if (merged) {
+      // more runs than the descriptor holds: one run over all covered bands (their cells are
+      // contiguous in the binned array) -- a superset of the window
+      const double pad = 1.0e-7 + 1.0e-6 * a.radius;
+      const int b0 = ag_band_of(a.grid, tlat + a.radius + pad), b1 = ag_band_of(a.grid, tlat - a.radius - pad);
+      d.first[0] = a.sstart[a.grid.off[b0]];
+      run = a.sstart[a.grid.off[b1 + 1]] - d.first[0];
+      d.incl[0] = run;
+      nruns = 1;
+    }
+    for (int j = nruns; j < AG_RADIUS_RUNS; ++j) {
+      d.first[j] = 0;
+      d.incl[j] = run;
+    }
+    d.unit = make_float4(tu.x, tu.y, tu.z, 0.0f);
+    a.desc[t] = d;
   }
-  return cnt;
 }
 
 __device__ __forceinline__ void ag_wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sources within the radius of target t, found by the whole wave from the target's descriptor:
+// returns the count; matching ids are stored (unsorted) at row[0 .. min(count, row_cap)) when row
+// is not null, and at spill[0 .. count) when spill is not null (rows too long for LDS).
+__device__ __forceinline__ int ag_radius_scan(const AgRadiusArgs& a, int64_t t, int* row, int row_cap,
+                                              int32_t* spill) {
+  const int lane = ag_lane();
+  const AgRadiusDesc* d = a.desc + t;
+  const int4 fa = *reinterpret_cast<const int4*>(&d->first[0]), fb = *reinterpret_cast<const int4*>(&d->first[4]);
+  const int4 ia = *reinterpret_cast<const int4*>(&d->incl[0]), ib = *reinterpret_cast<const int4*>(&d->incl[4]);
+  const float4 tu = d->unit;
+  const int total = ib.w;
+  int cnt = 0;
+  for (int q0 = 0; q0 < total; q0 += 128) {
+    // two candidates per lane and round: both loads are in flight before the first test
+    int q[2], id[2];
+    bool live[2], in[2];
+    float4 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      q[u] = q0 + 64 * u + lane;
+      live[u] = q[u] < total;
+      int first = fa.x, excl = 0;
+      if (q[u] >= ia.x) { first = fa.y; excl = ia.x; }
+      if (q[u] >= ia.y) { first = fa.z; excl = ia.y; }
+      if (q[u] >= ia.z) { first = fa.w; excl = ia.z; }
+      if (q[u] >= ia.w) { first = fb.x; excl = ia.w; }
+      if (q[u] >= ib.x) { first = fb.y; excl = ib.x; }
+      if (q[u] >= ib.y) { first = fb.z; excl = ib.y; }
+      if (q[u] >= ib.z) { first = fb.w; excl = ib.z; }
+      s[u] = live[u] ? a.spts[first + (q[u] - excl)] : make_float4(4.f, 4.f, 4.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      id[u] = __float_as_int(s[u].w);
+      const float dx = s[u].x - tu.x, dy = s[u].y - tu.y, dz = s[u].z - tu.z;
+      const float dd = dx * dx + dy * dy + dz * dz;
+      in[u] = live[u] && dd <= a.c_out;
+      if (in[u] && dd > a.c_in) {
+        const float2 tp = a.tgt[t];
+        const float2 sp = a.src[id[u]];
+        in[u] = ag_rdist(static_cast<double>(tp.x), static_cast<double>(tp.y), sp.x, sp.y) <= a.rthr;
+      }
+      const unsigned long long m = __ballot(in[u]);
+      if (in[u]) {
+        const int o = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (spill != nullptr) spill[o] = id[u];
+        else if (row != nullptr && o < row_cap) row[o] = id[u];
+      }
+      cnt += __popcll(m);
+    }
+  }
+  return cnt;
 }
 
 // Rank sort of the n <= AG_ROW_LDS distinct ids in `row` (LDS, room for n rounded up to 4) into out[0..n)
@@ -907,6 +954,16 @@ __device__ __forceinline__ void ag_row_rank_sort(int* row, int n, int32_t* __res
   if (lane < n4 - n) row[n + lane] = 0x7fffffff;  // pad to a multiple of 4 with a value that ranks last
   ag_wave_sync_lds();
   const int4* row4 = reinterpret_cast<const int4*>(row);
+  if (n <= 64) {  // one element per lane
+    const int v = lane < n ? row[lane] : 0x7fffffff;
+    int r = 0;
+    for (int j = 0; j < n4 / 4; ++j) {
+      const int4 q = row4[j];
+      r += (q.x < v) + (q.y < v) + (q.z < v) + (q.w < v);
+    }
+    if (lane < n) out[r] = v;
+    return;
+  }
   for (int e0 = 0; e0 < n; e0 += 128) {
     // two elements per lane share every broadcast read of four row entries
     const int ea = e0 + lane, eb = e0 + 64 + lane;
@@ -922,138 +979,57 @@ __device__ __forceinline__ void ag_row_rank_sort(int* row, int n, int32_t* __res
   }
 }
 
-#define AG_RADIUS_GROUP 64  // targets staged per block (a quarter per wave)
-#define AG_RADIUS_RUNS 8  // runs of binned sources a block-staged target can have (3 bands x 2 + spare)
-
-// Rank sort for rows of at most 64 entries: one element per lane
-__device__ __forceinline__ void ag_row_rank_sort64(int* row, int n, int32_t* __restrict__ out) {
-  const int lane = ag_lane();
-  const int n4 = (n + 3) & ~3;
-  if (lane < n4 - n) row[n + lane] = 0x7fffffff;
-  ag_wave_sync_lds();
-  const int4* row4 = reinterpret_cast<const int4*>(row);
-  const int v = lane < n ? row[lane] : 0x7fffffff;
-  int r = 0;
-  for (int j = 0; j < n4 / 4; ++j) {
-    const int4 q = row4[j];
-    r += (q.x < v) + (q.y < v) + (q.z < v) + (q.w < v);
-  }
-  if (lane < n) out[r] = v;
-}
-
-// Count pass.  A block takes AG_RADIUS_GROUP consecutive targets.  Phase A: one THREAD per target computes what
-// depends on the target only (float32 unit vector, the runs of binned sources its window covers)
-// into LDS, so the float64 window arithmetic is paid once per target, not once per wave
-// instruction.  Phase B: every wave walks through its quarter of the group; for each, the whole wave tests the
-// flattened candidate list, compacts the matching ids into its LDS row, and rows of at most
-// stash_cap entries are sorted and kept in the stash so that the fill pass does not search again.
+// Count pass: one wave per target counts its row; rows of at most stash_cap entries are sorted and
+// kept in the stash so that the fill pass does not search again.
 __global__ __launch_bounds__(256) void ag_radius_count_kernel(AgRadiusArgs a) {
   __shared__ __attribute__((aligned(16))) int row_all[4][AG_STASH_MAX + 4];
-  __shared__ __attribute__((aligned(16))) int t_first[AG_RADIUS_GROUP][AG_RADIUS_RUNS];
-  __shared__ __attribute__((aligned(16))) int t_incl[AG_RADIUS_GROUP][AG_RADIUS_RUNS];
-  __shared__ float4 t_unit[AG_RADIUS_GROUP];  // w: 1 when the target needs the wave-level search (too many runs)
   const int lane = ag_lane();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int* row = row_all[wave];
-  for (int64_t t0 = int64_t(blockIdx.x) * AG_RADIUS_GROUP; t0 < a.nt; t0 += int64_t(gridDim.x) * AG_RADIUS_GROUP) {
-    {  // phase A
-      const int i = threadIdx.x;
-      const int64_t t = t0 + i;
-      if (i < AG_RADIUS_GROUP && t < a.nt) {
-        const float2 tpf = a.tgt[t];
-        const float3 tu = ag_unit_vec(tpf.x, tpf.y);
-        const double tlat = tpf.x, tlonw = ag_wrap_lon(static_cast<double>(tpf.y));
-        int run = 0, nruns = 1;
-        bool slow = false;
-        for (int j = 0; j < nruns; ++j) {
-          int first, last;
-          nruns = ag_lane_range(a.grid, a.sstart, tlat, tlonw, a.radius, j, &first, &last);
-          if (nruns > AG_RADIUS_RUNS) {
-            slow = true;
-            break;
-          }
-          run += last - first;
-          t_first[i][j] = first;
-          t_incl[i][j] = run;
-        }
-        for (int j = slow ? 0 : nruns; j < AG_RADIUS_RUNS; ++j) {
-          t_first[i][j] = 0;
-          t_incl[i][j] = slow ? 0 : run;
-        }
-        t_unit[i] = make_float4(tu.x, tu.y, tu.z, slow ? 1.0f : 0.0f);
-      }
+  const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t t = wave_global; t < a.nt; t += nwaves) {
+    const int cnt = ag_radius_scan(a, t, a.stash_cap > 0 ? row : nullptr, a.stash_cap, nullptr);
+    if (lane == 0) a.offsets[t] = cnt;
+    if (cnt > 0 && cnt <= a.stash_cap) {
+      ag_wave_sync_lds();
+      ag_row_rank_sort(row, cnt, a.stash + t * a.stash_cap);
     }
-    __syncthreads();
-    // phase B
-    int my_count = 0;
-    constexpr int per_wave = AG_RADIUS_GROUP / 4;
-    const int i_end = static_cast<int>(min(int64_t(per_wave), a.nt - t0 - wave * per_wave));
-    for (int k = 0; k < i_end; ++k) {
-      const int i = wave * per_wave + k;
-      const int64_t t = t0 + i;
-      const float4 tu = t_unit[i];
-      int cnt = 0;
-      if (tu.w != 0.0f) {
-        cnt = static_cast<int>(min(ag_radius_search(a, t, a.stash_cap > 0 ? row : nullptr, a.stash_cap, nullptr),
-                                   int64_t(0x7fffffff)));
-      } else {
-        const int4 fa = *reinterpret_cast<const int4*>(&t_first[i][0]), fb = *reinterpret_cast<const int4*>(&t_first[i][4]);
-        const int4 ia = *reinterpret_cast<const int4*>(&t_incl[i][0]), ib = *reinterpret_cast<const int4*>(&t_incl[i][4]);
-        const int total = ib.w;
-        float2 tpf = make_float2(0.f, 0.f);
-        bool have_tp = false;
-        for (int q0 = 0; q0 < total; q0 += 64) {
-          const int q = q0 + lane;
-          bool in = false;
-          int id = 0;
-          if (q < total) {
-            // run of candidate q and its position in the binned array
-            int first = fa.x, excl = 0;
-            if (q >= ia.x) { first = fa.y; excl = ia.x; }
-            if (q >= ia.y) { first = fa.z; excl = ia.y; }
-            if (q >= ia.z) { first = fa.w; excl = ia.z; }
-            if (q >= ia.w) { first = fb.x; excl = ia.w; }
-            if (q >= ib.x) { first = fb.y; excl = ib.x; }
-            if (q >= ib.y) { first = fb.z; excl = ib.y; }
-            if (q >= ib.z) { first = fb.w; excl = ib.z; }
-            const float4 s = a.spts[first + (q - excl)];
-            id = __float_as_int(s.w);
-            const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
-            const float d = dx * dx + dy * dy + dz * dz;
-            in = d <= a.c_out;
-            if (in && d > a.c_in) {
-              if (!have_tp) {
-                tpf = a.tgt[t];
-                have_tp = true;
-              }
-              const float2 sp = a.src[id];
-              in = ag_rdist(static_cast<double>(tpf.x), static_cast<double>(tpf.y), sp.x, sp.y) <= a.rthr;
-            }
-          }
-          const unsigned long long m = __ballot(in);
-          if (in) {
-            const int o = cnt + __popcll(m & ((1ull << lane) - 1ull));
-            if (o < a.stash_cap) row[o] = id;
-          }
-          cnt += __popcll(m);
-        }
-      }
-      if (lane == k) my_count = cnt;
-      if (cnt > 0 && cnt <= a.stash_cap) {
-        ag_wave_sync_lds();
-        if (cnt <= 64) ag_row_rank_sort64(row, cnt, a.stash + t * a.stash_cap);
-        else ag_row_rank_sort(row, cnt, a.stash + t * a.stash_cap);
-      }
-      ag_wave_sync_lds();  // the row is reused by the next target
-    }
-    if (lane < i_end) a.offsets[t0 + wave * per_wave + lane] = my_count;
-    __syncthreads();  // the staged targets are overwritten by the next group
+    ag_wave_sync_lds();  // the row is reused by the next target
   }
 }
 
-// Fill pass: rows kept by the count pass are copied; longer rows are searched again, sorted in LDS
-// (up to AG_ROW_LDS entries) or in place in global memory.
-__global__ __launch_bounds__(256) void ag_radius_fill_kernel(AgRadiusArgs a) {
+#define AG_COPY_GROUP 64  // targets per block of the copy kernel
+
+// Fill pass, rows kept by the count pass: a block copies the rows of AG_COPY_GROUP consecutive
+// targets; its threads stride over the block's contiguous piece of the output and find their row
+// by binary search among the group's offsets (LDS).
+__global__ __launch_bounds__(256) void ag_radius_copy_kernel(AgRadiusArgs a) {
+  __shared__ int64_t off[AG_COPY_GROUP + 1];
+  for (int64_t t0 = int64_t(blockIdx.x) * AG_COPY_GROUP; t0 < a.nt; t0 += int64_t(gridDim.x) * AG_COPY_GROUP) {
+    const int n = static_cast<int>(min(int64_t(AG_COPY_GROUP), a.nt - t0));
+    if (threadIdx.x <= n) off[threadIdx.x] = a.offsets[t0 + threadIdx.x];
+    __syncthreads();
+    const int64_t e_begin = off[0], e_end = off[n];
+    for (int64_t e = e_begin + threadIdx.x; e < e_end; e += blockDim.x) {
+      int lo = 0, hi = n - 1;  // last row whose offset is <= e
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      const int64_t t = t0 + lo;
+      if (off[lo + 1] - off[lo] <= a.stash_cap) {
+        a.out_src[e] = a.stash[t * a.stash_cap + (e - off[lo])];
+        a.out_tgt[e] = static_cast<int32_t>(t);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Fill pass, rows longer than the stash: searched again, sorted in LDS (up to AG_ROW_LDS entries)
+// or in place in global memory.
+__global__ __launch_bounds__(256) void ag_radius_long_kernel(AgRadiusArgs a) {
   __shared__ __attribute__((aligned(16))) int row_all[4][AG_ROW_LDS + 4];
   const int lane = ag_lane();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1063,16 +1039,9 @@ __global__ __launch_bounds__(256) void ag_radius_fill_kernel(AgRadiusArgs a) {
   for (int64_t t = wave_global; t < a.nt; t += nwaves) {
     const int64_t base_out = a.offsets[t];
     const int64_t n_row = a.offsets[t + 1] - base_out;
-    if (n_row <= a.stash_cap) {
-      const int32_t* kept = a.stash + t * a.stash_cap;
-      for (int e = lane; e < n_row; e += 64) {
-        a.out_src[base_out + e] = kept[e];
-        a.out_tgt[base_out + e] = static_cast<int32_t>(t);
-      }
-      continue;
-    }
+    if (n_row <= a.stash_cap) continue;
     if (n_row <= AG_ROW_LDS) {
-      (void)ag_radius_search(a, t, row, AG_ROW_LDS, nullptr);
+      (void)ag_radius_scan(a, t, row, AG_ROW_LDS, nullptr);
       ag_wave_sync_lds();
       ag_row_rank_sort(row, static_cast<int>(n_row), a.out_src + base_out);
       for (int e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
@@ -1080,7 +1049,7 @@ __global__ __launch_bounds__(256) void ag_radius_fill_kernel(AgRadiusArgs a) {
     } else {
       // the target column doubles as scratch for long rows; source ids are distinct inside a
       // row, so rank = number of smaller ids
-      (void)ag_radius_search(a, t, nullptr, 0, a.out_tgt + base_out);
+      (void)ag_radius_scan(a, t, nullptr, 0, a.out_tgt + base_out);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
       for (int64_t e = lane; e < n_row; e += 64) {
@@ -1102,6 +1071,7 @@ struct AgRadiusWs {
   size_t scan_temp_bytes;
   int32_t* stash;
   int stash_cap;
+  AgRadiusDesc* desc;
 };
 
 // cell size for a radius query: the query radius itself, but never so small that the grid has
@@ -1135,7 +1105,9 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
   void* st = c.take<char>(stb);
   const int cap = ag_radius_stash_cap(nt);
   int32_t* stash = c.take<int32_t>(nt * cap + 4);
+  AgRadiusDesc* desc = c.take<AgRadiusDesc>(nt);
   if (w) {
+    w->desc = desc;
     w->scan_temp = st;
     w->scan_temp_bytes = stb;
     w->stash = stash;
@@ -1161,6 +1133,7 @@ static int ag_radius_args(const float* d_src, const float* d_tgt, int64_t nt, do
   a->nt = nt;
   a->stash = w.stash;
   a->stash_cap = w.stash_cap;
+  a->desc = w.desc;
   a->radius = radius < AG_PI ? radius : AG_PI;
   const double s = sin(0.5 * radius);
   a->rthr = s * s;
@@ -1195,7 +1168,9 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
   a.out_src = nullptr;
   a.out_tgt = nullptr;
   if (nt > 0) {
-    AG_KERNEL("ag_radius_count_kernel", ag_radius_count_kernel, dim3(ag_blocks(nt, AG_RADIUS_GROUP, 65536)), dim3(256), s, a);
+    AG_KERNEL("ag_radius_window_kernel", ag_radius_window_kernel, dim3(ag_blocks(nt, 256, 16384)), dim3(256), s, a);
+    AG_LAUNCH_CHECK();
+    AG_KERNEL("ag_radius_count_kernel", ag_radius_count_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
   return ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
@@ -1218,7 +1193,11 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
   a.offsets = const_cast<int64_t*>(d_offsets);
   a.out_src = d_out_src;
   a.out_tgt = d_out_tgt;
-  AG_KERNEL("ag_radius_fill_kernel", ag_radius_fill_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
+  if (a.stash_cap > 0) {
+    AG_KERNEL("ag_radius_copy_kernel", ag_radius_copy_kernel, dim3(ag_blocks(nt, AG_COPY_GROUP, 16384)), dim3(256), s, a);
+    AG_LAUNCH_CHECK();
+  }
+  AG_KERNEL("ag_radius_long_kernel", ag_radius_long_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
