@@ -358,6 +358,9 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
 size_t ag_sort_u64_temp_bytes(int64_t n);
 int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t* d_out, int64_t n, int begin_bit,
                 int end_bit, hipStream_t stream);
+size_t ag_sort_pairs_u64_i32_temp_bytes(int64_t n);
+int ag_sort_pairs_u64_i32(void* d_temp, size_t temp_bytes, const uint64_t* d_keys_in, uint64_t* d_keys_out,
+                          const int32_t* d_vals_in, int32_t* d_vals_out, int64_t n, hipStream_t stream);
 size_t ag_scan_i32_temp_bytes(int64_t n);
 // exclusive prefix sum of n int32 values, in place allowed
 int ag_exclusive_scan_i32(void* d_temp, size_t temp_bytes, const int* d_in, int* d_out, int64_t n, hipStream_t stream);

@@ -4,10 +4,14 @@
 // unique undirected edge after the existing vertices -- unique edges enumerated in increasing
 // order of (max vertex, min vertex) -- splits each face (a,b,c) into (a,ab,ca) (ab,b,bc)
 // (ca,bc,c) (ab,bc,ca), and then pushes ALL vertices back to the unit sphere in float64.
-// On the GPU one level is: pack the 3F half-edges into 64-bit keys, radix-sort them (every
-// edge of the closed mesh then appears exactly twice, so entry 2i is unique edge i), one thread
-// per unique edge writes the midpoint, one thread per face finds its three midpoints by binary
-// search in the sorted edge list and writes the four child faces.
+// On the GPU one level needs no sort.  In the closed, consistently oriented mesh every edge
+// appears once as a half-edge (a, b) with a > b; those half-edges are collected per larger vertex
+// a (at most 6 per vertex, one atomic slot counter each), a prefix sum over the counters gives
+// every vertex the position of its first edge, and sorting the <= 6 smaller neighbours of a
+// vertex in registers yields exactly the (max vertex, min vertex) order.  One thread per vertex
+// writes its unique edges and their midpoints; one thread per face finds its three midpoints by
+// looking the smaller endpoint up among the <= 6 neighbours of the larger one and writes the
+// four child faces.
 #include <string.h>
 
 #include "ag_common.hpp"
@@ -30,6 +34,12 @@ static inline int64_t ag_ico_F(int l) { return 20 * (int64_t(1) << (2 * l)); }
 static inline int64_t ag_ico_E(int l) { return 30 * (int64_t(1) << (2 * l)); }
 // offset of level l in the concatenated per-level unique-edge array: sum of E_j for j < l
 static inline int64_t ag_ico_edge_offset(int l) { return 10 * ((int64_t(1) << (2 * l)) - 1); }
+// bits needed for a vertex id of level l (1 << bits > V_l)
+static inline int ag_vertex_bits(int l) {
+  int bits = 1;
+  while ((int64_t(1) << bits) <= ag_ico_V(l)) ++bits;
+  return bits;
+}
 
 __global__ void ag_ico_init_kernel(double* __restrict__ xyz, int32_t* __restrict__ faces) {
   const int i = threadIdx.x;
@@ -52,50 +62,88 @@ __device__ __forceinline__ uint64_t ag_edge_key(int a, int b) {
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-__global__ void ag_ico_edge_keys_kernel(const int32_t* __restrict__ faces, int64_t F, uint64_t* __restrict__ keys) {
+// half-edges (a, b) with a > b: slot of b among the smaller neighbours of a
+__global__ void ag_ico_lower_kernel(const int32_t* __restrict__ faces, int64_t F, int* __restrict__ cnt,
+                                    int32_t* __restrict__ nb, int* __restrict__ error_flag) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < 3 * F; i += int64_t(gridDim.x) * blockDim.x) {
     const int64_t f = i / 3;
     const int j = static_cast<int>(i - 3 * f);
     const int a = faces[3 * f + j], b = faces[3 * f + (j == 2 ? 0 : j + 1)];
-    keys[i] = ag_edge_key(a, b);
+    if (a > b) {
+      const int slot = atomicAdd(&cnt[a], 1);
+      if (slot < AG_MAX_DEG) nb[AG_MAX_DEG * int64_t(a) + slot] = b;
+      else *error_flag = 1;
+    }
   }
 }
 
-// sorted half-edge keys -> unique edges (every edge of the closed mesh appears exactly twice)
-__global__ void ag_ico_unique_kernel(const uint64_t* __restrict__ sorted, int64_t Eu, uint64_t* __restrict__ uniq,
-                                     int* __restrict__ error_flag) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < Eu; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint64_t k = sorted[2 * i];
-    if (k != sorted[2 * i + 1]) *error_flag = 1;
-    uniq[i] = k;
+__device__ __forceinline__ void ag_cswap(int& x, int& y) {
+  const int lo = min(x, y), hi = max(x, y);
+  x = lo;
+  y = hi;
+}
+
+// One thread per vertex a: sort its smaller neighbours, write them back, emit the unique edges
+// (a, b_j) at first[a] + j and (optionally) their midpoints as vertices V + first[a] + j.
+__global__ void ag_ico_emit_kernel(int64_t V, int64_t Eu, const int* __restrict__ first, int32_t* __restrict__ nb,
+                                   uint64_t* __restrict__ uniq, double* __restrict__ xyz, int write_midpoints,
+                                   int* __restrict__ error_flag) {
+  for (int64_t a = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; a < V; a += int64_t(gridDim.x) * blockDim.x) {
+    if (a == 0 && first[V] != Eu) *error_flag = 1;  // not a closed, consistently oriented mesh
+    const int base = first[a];
+    const int n = min(first[a + 1] - base, AG_MAX_DEG);
+    int32_t* mine = nb + AG_MAX_DEG * a;
+    int v0 = n > 0 ? mine[0] : 0x7fffffff, v1 = n > 1 ? mine[1] : 0x7fffffff, v2 = n > 2 ? mine[2] : 0x7fffffff;
+    int v3 = n > 3 ? mine[3] : 0x7fffffff, v4 = n > 4 ? mine[4] : 0x7fffffff, v5 = n > 5 ? mine[5] : 0x7fffffff;
+    // 12-comparator sorting network for 6 values
+    ag_cswap(v0, v5); ag_cswap(v1, v3); ag_cswap(v2, v4);
+    ag_cswap(v1, v2); ag_cswap(v3, v4);
+    ag_cswap(v0, v3); ag_cswap(v2, v5);
+    ag_cswap(v0, v1); ag_cswap(v2, v3); ag_cswap(v4, v5);
+    ag_cswap(v1, v2); ag_cswap(v3, v4);
+    const int v[AG_MAX_DEG] = {v0, v1, v2, v3, v4, v5};
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (write_midpoints) {
+      ax = xyz[3 * a];
+      ay = xyz[3 * a + 1];
+      az = xyz[3 * a + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < AG_MAX_DEG; ++j) {
+      if (j < n) {
+        const int b = v[j];
+        mine[j] = b;
+        const int64_t i = base + j;
+        uniq[i] = (static_cast<uint64_t>(static_cast<uint32_t>(a)) << 32) | static_cast<uint32_t>(b);
+        if (write_midpoints) {
+          xyz[3 * (V + i)] = (ax + xyz[3 * int64_t(b)]) / 2.0;
+          xyz[3 * (V + i) + 1] = (ay + xyz[3 * int64_t(b) + 1]) / 2.0;
+          xyz[3 * (V + i) + 2] = (az + xyz[3 * int64_t(b) + 2]) / 2.0;
+        }
+      }
+    }
   }
 }
 
-__global__ void ag_ico_midpoints_kernel(const uint64_t* __restrict__ uniq, int64_t Eu, int64_t V,
-                                        double* __restrict__ xyz) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < Eu; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint64_t k = uniq[i];
-    const int64_t a = static_cast<uint32_t>(k), b = static_cast<uint32_t>(k >> 32);
-    for (int c = 0; c < 3; ++c) xyz[3 * (V + i) + c] = (xyz[3 * a + c] + xyz[3 * b + c]) / 2.0;
-  }
+// index of the unique edge {x, y}: position of the smaller endpoint among the sorted smaller
+// neighbours of the larger one
+__device__ __forceinline__ int ag_edge_index(const int* __restrict__ first, const int32_t* __restrict__ nb, int x, int y) {
+  const int hi = max(x, y), lo = min(x, y);
+  const int32_t* mine = nb + AG_MAX_DEG * int64_t(hi);
+  const int n = first[hi + 1] - first[hi];
+  int pos = 0;
+#pragma unroll
+  for (int j = 0; j < AG_MAX_DEG; ++j) pos += (j < n && mine[j] < lo) ? 1 : 0;
+  return first[hi] + pos;
 }
 
-__device__ __forceinline__ int ag_find_edge(const uint64_t* __restrict__ uniq, int64_t Eu, uint64_t key) {
-  int64_t lo = 0, hi = Eu;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (uniq[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  return static_cast<int>(lo);
-}
-
-__global__ void ag_ico_subdivide_kernel(const int32_t* __restrict__ fin, int64_t F, const uint64_t* __restrict__ uniq,
-                                        int64_t Eu, int V, int32_t* __restrict__ fout) {
+__global__ void ag_ico_subdivide_kernel(const int32_t* __restrict__ fin, int64_t F, const int* __restrict__ first,
+                                        const int32_t* __restrict__ nb, int V, int32_t* __restrict__ fout) {
   for (int64_t f = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; f < F; f += int64_t(gridDim.x) * blockDim.x) {
     const int a = fin[3 * f], b = fin[3 * f + 1], c = fin[3 * f + 2];
-    const int m0 = V + ag_find_edge(uniq, Eu, ag_edge_key(a, b));
-    const int m1 = V + ag_find_edge(uniq, Eu, ag_edge_key(b, c));
-    const int m2 = V + ag_find_edge(uniq, Eu, ag_edge_key(c, a));
+    const int m0 = V + ag_edge_index(first, nb, a, b);
+    const int m1 = V + ag_edge_index(first, nb, b, c);
+    const int m2 = V + ag_edge_index(first, nb, c, a);
     int32_t* o = fout + 12 * f;
     o[0] = a;  o[1] = m0; o[2] = m2;
     o[3] = m0; o[4] = b;  o[5] = m1;
@@ -127,24 +175,17 @@ __global__ void ag_ico_final_edges_kernel(const uint64_t* __restrict__ parent_ed
   }
 }
 
-__global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V) {
+// (also clears the slot counters for the next level: V + 1 of them)
+__global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V, int* __restrict__ cnt) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
+    cnt[i] = 0;
+    if (i == 0) cnt[V] = 0;
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const double s = sqrt(x * x + y * y + z * z);
     const double off = 1.0 - s;
     xyz[3 * i] = x + (x / s) * off;
     xyz[3 * i + 1] = y + (y / s) * off;
     xyz[3 * i + 2] = z + (z / s) * off;
-  }
-}
-
-// generate/transforms.py:50-52
-__global__ void ag_ico_latlon_kernel(const double* __restrict__ xyz, int64_t V, float2* __restrict__ latlon) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
-    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const double lat = asin(z / (x * x + y * y + z * z));
-    const double lon = atan2(y, x);
-    latlon[i] = make_float2(static_cast<float>(lat), static_cast<float>(lon));
   }
 }
 
@@ -156,82 +197,81 @@ __device__ __forceinline__ uint32_t ag_desc_key(float v) {
   return ~u;                                        // descending
 }
 
-// Node order = latitude descending, ties longitude descending, ties vertex id descending, as two
-// full-width 64-bit sorts (no reliance on partial-bit sorting):
-//   pass 0 key = (descending-longitude key << 32) | (0xffffffff - id)
-//   pass 1 key = (descending-latitude key  << 32) | position after pass 0
-__global__ void ag_ico_order_keys0_kernel(const float2* __restrict__ latlon, int64_t V, uint64_t* __restrict__ keys) {
+// generate/transforms.py:50-52, plus the node-order sort input: position p holds vertex
+// id = V - 1 - p (descending ids, so that the stable sort breaks ties towards the larger id) with
+// key = (descending-latitude key << 32) | descending-longitude key
+__global__ void ag_ico_latlon_kernel(const double* __restrict__ xyz, int64_t V, float2* __restrict__ latlon,
+                                     uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint32_t id = static_cast<uint32_t>(i);
-    keys[i] = (static_cast<uint64_t>(ag_desc_key(latlon[i].y)) << 32) | (0xffffffffu - id);
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const double lat = asin(z / (x * x + y * y + z * z));
+    const double lon = atan2(y, x);
+    const float2 p = make_float2(static_cast<float>(lat), static_cast<float>(lon));
+    latlon[i] = p;
+    const int64_t pos = V - 1 - i;
+    keys[pos] = (static_cast<uint64_t>(ag_desc_key(p.x)) << 32) | ag_desc_key(p.y);
+    ids[pos] = static_cast<int32_t>(i);
   }
 }
 
-__global__ void ag_ico_order_keys1_kernel(const float2* __restrict__ latlon, int64_t V,
-                                          const uint64_t* __restrict__ sorted0, uint64_t* __restrict__ keys) {
+__global__ void ag_ico_finish_order_kernel(const int32_t* __restrict__ order, const float2* __restrict__ latlon, int64_t V,
+                                           float2* __restrict__ out_latlon, int32_t* __restrict__ rank) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint32_t id = 0xffffffffu - static_cast<uint32_t>(sorted0[i]);
-    keys[i] = (static_cast<uint64_t>(ag_desc_key(latlon[id].x)) << 32) | static_cast<uint32_t>(i);
-  }
-}
-
-__global__ void ag_ico_finish_order_kernel(const uint64_t* __restrict__ sorted0, const uint64_t* __restrict__ sorted1,
-                                           const float2* __restrict__ latlon, int64_t V,
-                                           float2* __restrict__ out_latlon, int32_t* __restrict__ order,
-                                           int32_t* __restrict__ rank) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint32_t pos0 = static_cast<uint32_t>(sorted1[i]);
-    const uint32_t id = 0xffffffffu - static_cast<uint32_t>(sorted0[pos0]);
-    order[i] = static_cast<int32_t>(id);
+    const int32_t id = order[i];
     rank[id] = static_cast<int32_t>(i);
     out_latlon[i] = latlon[id];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// host side: topology stepping shared by ag_icosphere and ag_multiscale_*
+// host side
 // ---------------------------------------------------------------------------------------------
 struct AgTopoWs {
-  uint64_t* keys_a;   // [3 F_R]
-  uint64_t* keys_b;   // [3 F_R]
-  uint64_t* uniq;     // [E_R]
+  int* first;          // [V_R + 2] slot counters, then first-edge offsets of every vertex
+  int32_t* nb;         // [6 V_R]   smaller neighbours of every vertex
+  void* scan_temp;
+  size_t scan_temp_bytes;
+  uint64_t* uniq;      // [E_R]     unique edges of a level when the caller does not keep them
+  uint64_t* keys_a;    // [V_R]     node-order sort keys
+  uint64_t* keys_b;    // [V_R]
+  int32_t* ids_a;      // [V_R]     node-order sort values
   void* sort_temp;
   size_t sort_temp_bytes;
-  int32_t* faces_a;   // [3 F_R]
-  int32_t* faces_b;   // [3 F_R]
+  int32_t* faces_a;    // [3 F_R]
   int* error_flag;
 };
 
-static void ag_topo_carve(AgCarver& c, int R, bool two_face_buffers, AgTopoWs* w) {
-  const int64_t F = ag_ico_F(R);
+static void ag_topo_carve(AgCarver& c, int R, AgTopoWs* w) {
+  const int64_t F = ag_ico_F(R), V = ag_ico_V(R);
   AgTopoWs t;
-  t.keys_a = c.take<uint64_t>(3 * F);
-  t.keys_b = c.take<uint64_t>(3 * F);
+  t.first = c.take<int>(V + 2);
+  t.nb = c.take<int32_t>(AG_MAX_DEG * V);
+  t.scan_temp_bytes = ag_scan_i32_temp_bytes(V + 2);
+  t.scan_temp = c.take<char>(t.scan_temp_bytes);
   t.uniq = c.take<uint64_t>(ag_ico_E(R));
-  t.sort_temp_bytes = ag_sort_u64_temp_bytes(3 * F);
+  t.keys_a = c.take<uint64_t>(V);
+  t.keys_b = c.take<uint64_t>(V);
+  t.ids_a = c.take<int32_t>(V);
+  t.sort_temp_bytes = ag_sort_pairs_u64_i32_temp_bytes(V);
   t.sort_temp = c.take<char>(t.sort_temp_bytes);
   t.faces_a = c.take<int32_t>(3 * F);
-  t.faces_b = two_face_buffers ? c.take<int32_t>(3 * F) : nullptr;
   t.error_flag = c.take<int>(4);
   if (w) *w = t;
 }
 
-static int ag_vertex_bits(int l) {
-  int bits = 1;
-  while ((int64_t(1) << bits) <= ag_ico_V(l)) ++bits;
-  return bits;
-}
-
-// unique edges of `faces` (level l) into `uniq`
-static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, uint64_t* uniq, hipStream_t s) {
-  const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l);
-  AG_KERNEL("ag_ico_edge_keys_kernel", ag_ico_edge_keys_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), s, faces,
-            F, w.keys_a);
+// unique edges of `faces` (level l) into `uniq`, in (max vertex, min vertex) order; leaves the
+// per-vertex offsets and sorted neighbour lists in the workspace for the subdivision.  The slot
+// counters w.first[0 .. V_l] must be zero on entry.
+static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, uint64_t* uniq, double* xyz,
+                                bool write_midpoints, hipStream_t s) {
+  const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
+  AG_KERNEL("ag_ico_lower_kernel", ag_ico_lower_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), s, faces, F,
+            w.first, w.nb, w.error_flag);
   AG_LAUNCH_CHECK();
-  int rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, 3 * F, 0, 32 + ag_vertex_bits(l), s);
+  int rc = ag_exclusive_scan_i32(w.scan_temp, w.scan_temp_bytes, w.first, w.first, V + 1, s);
   if (rc) return rc;
-  AG_KERNEL("ag_ico_unique_kernel", ag_ico_unique_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, w.keys_b, Eu,
-            uniq, w.error_flag);
+  AG_KERNEL("ag_ico_emit_kernel", ag_ico_emit_kernel, dim3(ag_blocks(V, 256, 8192)), dim3(256), s, V, Eu, w.first, w.nb,
+            uniq, xyz, write_midpoints ? 1 : 0, w.error_flag);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -247,7 +287,7 @@ extern "C" int ag_icosphere_sizes(int R, int64_t* V, int64_t* F, int64_t* E_all)
 extern "C" size_t ag_icosphere_workspace_bytes(int R) {
   if (R < 0 || R > AG_ICO_MAX_LEVEL) return 0;
   AgCarver c(nullptr);
-  ag_topo_carve(c, R, false, nullptr);
+  ag_topo_carve(c, R, nullptr);
   (void)c.take<float2>(ag_ico_V(R));
   return c.total();
 }
@@ -260,12 +300,14 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   hipStream_t s = static_cast<hipStream_t>(stream);
   AgCarver c(d_ws);
   AgTopoWs w;
-  ag_topo_carve(c, R, false, &w);
+  ag_topo_carve(c, R, &w);
   float2* latlon = c.take<float2>(ag_ico_V(R));
   // ping-pong between the caller's face buffer and the workspace so that level R lands in d_faces
   int32_t* cur = (R % 2 == 0) ? d_faces : w.faces_a;
   int32_t* nxt = (R % 2 == 0) ? w.faces_a : d_faces;
   int rc = ag_zero_i32(w.error_flag, 1, s);
+  if (rc) return rc;
+  rc = ag_zero_i32(w.first, ag_ico_V(0) + 1, s);
   if (rc) return rc;
   AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, d_xyz, cur);
   AG_LAUNCH_CHECK();
@@ -273,16 +315,13 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
     const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
     // the unique edges of level l go straight into the per-level edge array when the caller wants it
     uint64_t* uniq = d_level_edges ? d_level_edges + ag_ico_edge_offset(l) : w.uniq;
-    rc = ag_topo_unique_edges(w, cur, l, uniq, s);
+    rc = ag_topo_unique_edges(w, cur, l, uniq, d_xyz, true, s);
     if (rc) return rc;
-    AG_KERNEL("ag_ico_midpoints_kernel", ag_ico_midpoints_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, uniq,
-              Eu, V, d_xyz);
-    AG_LAUNCH_CHECK();
     AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F,
-              uniq, Eu, static_cast<int>(V), nxt);
+              w.first, w.nb, static_cast<int>(V), nxt);
     AG_LAUNCH_CHECK();
     AG_KERNEL("ag_ico_project_kernel", ag_ico_project_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), s, d_xyz,
-              V + Eu);
+              V + Eu, w.first);
     AG_LAUNCH_CHECK();
     if (d_level_edges && l == R - 1) {
       AG_KERNEL("ag_ico_final_edges_kernel", ag_ico_final_edges_kernel, dim3(ag_blocks(Eu + F, 256, 8192)), dim3(256),
@@ -294,26 +333,19 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
     nxt = t;
   }
   if (d_level_edges && R == 0) {
-    rc = ag_topo_unique_edges(w, cur, 0, d_level_edges, s);
+    rc = ag_topo_unique_edges(w, cur, 0, d_level_edges, d_xyz, false, s);
     if (rc) return rc;
   }
   const int64_t V = ag_ico_V(R);
   const int vb = ag_blocks(V, 256, 8192);
-  AG_KERNEL("ag_ico_latlon_kernel", ag_ico_latlon_kernel, dim3(vb), dim3(256), s, d_xyz, V, latlon);
+  AG_KERNEL("ag_ico_latlon_kernel", ag_ico_latlon_kernel, dim3(vb), dim3(256), s, d_xyz, V, latlon, w.keys_a, w.ids_a);
   AG_LAUNCH_CHECK();
-  // node order: latitude descending, ties longitude descending, ties vertex id descending
-  uint64_t* sorted0 = w.uniq;  // E_R >= V_R entries
-  AG_KERNEL("ag_ico_order_keys0_kernel", ag_ico_order_keys0_kernel, dim3(vb), dim3(256), s, latlon, V, w.keys_a);
-  AG_LAUNCH_CHECK();
-  rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, sorted0, V, 0, 64, s);
+  // node order: latitude descending, ties longitude descending, ties vertex id descending -- one
+  // stable sort of (latitude key, longitude key) pairs presented in descending id order
+  rc = ag_sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.ids_a, d_order, V, s);
   if (rc) return rc;
-  AG_KERNEL("ag_ico_order_keys1_kernel", ag_ico_order_keys1_kernel, dim3(vb), dim3(256), s, latlon, V, sorted0,
-            w.keys_a);
-  AG_LAUNCH_CHECK();
-  rc = ag_sort_u64(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, V, 0, 64, s);
-  if (rc) return rc;
-  AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, sorted0, w.keys_b, latlon,
-            V, reinterpret_cast<float2*>(d_latlon), d_order, d_rank);
+  AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, d_order, latlon, V,
+            reinterpret_cast<float2*>(d_latlon), d_rank);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -321,26 +353,46 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
 // ---------------------------------------------------------------------------------------------
 // multi-scale edges
 // ---------------------------------------------------------------------------------------------
-#define AG_NO_PAIR 0xffffffffffffffffull
-
 static inline int ag_hops_capacity(int x_hops) { return 3 * x_hops * (x_hops + 1); }
 
-__device__ __forceinline__ uint64_t ag_pair_key(int src_node, int tgt_node) {
-  return (static_cast<uint64_t>(static_cast<uint32_t>(tgt_node)) << 32) | static_cast<uint32_t>(src_node);
+// Pair keys are (target rank << B) | source rank with B = bits of the node count, so that the sort
+// only has to look at 2B bits; the all-ones 2B-bit value is larger than every real key and marks
+// an unused slot.
+__device__ __forceinline__ uint64_t ag_pair_key(int src_node, int tgt_node, int B) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(tgt_node)) << B) | static_cast<uint32_t>(src_node);
 }
+__host__ __device__ __forceinline__ uint64_t ag_no_pair(int B) { return (uint64_t(1) << (2 * B)) - 1; }
 
-// x_hops == 1: both directions of every (active) mesh edge, one fixed pair of slots per edge
-__global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ edges, int64_t Eu, const uint8_t* __restrict__ active,
-                                        const int32_t* __restrict__ rank, uint64_t* __restrict__ pairs) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < Eu; i += int64_t(gridDim.x) * blockDim.x) {
-    const uint64_t k = edges[i];
+#define AG_MS_MAX_LEVELS (AG_ICO_MAX_LEVEL + 1)
+struct AgMsLevels {
+  int n;
+  int64_t edge_off[AG_MS_MAX_LEVELS];  // offset of the level in the per-level edge array
+  int64_t end[AG_MS_MAX_LEVELS];       // running total of edges over the selected levels
+};
+
+// x_hops == 1: both directions of every (active) mesh edge of every selected level, one fixed pair
+// of slots per edge (one launch for all levels)
+__global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ level_edges, AgMsLevels lv,
+                                        const uint8_t* __restrict__ active, const int32_t* __restrict__ rank, int B,
+                                        uint64_t* __restrict__ pairs) {
+  const int64_t total = lv.end[lv.n - 1];
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    int64_t start = 0, eoff = lv.edge_off[0];
+#pragma unroll
+    for (int j = 1; j < AG_MS_MAX_LEVELS; ++j) {
+      if (i >= lv.end[j - 1]) {  // never true past the last selected level: end[] is padded with the total
+        start = lv.end[j - 1];
+        eoff = lv.edge_off[j];
+      }
+    }
+    const uint64_t k = level_edges[eoff + (i - start)];
     const int a = static_cast<int>(static_cast<uint32_t>(k)), b = static_cast<int>(static_cast<uint32_t>(k >> 32));
-    uint64_t p0 = AG_NO_PAIR, p1 = AG_NO_PAIR;
+    uint64_t p0 = ag_no_pair(B), p1 = ag_no_pair(B);
     if (active == nullptr || (active[a] && active[b])) {
       const int ra = rank[a], rb = rank[b];
       if (ra >= 0 && rb >= 0) {
-        p0 = ag_pair_key(ra, rb);
-        p1 = ag_pair_key(rb, ra);
+        p0 = ag_pair_key(ra, rb, B);
+        p1 = ag_pair_key(rb, ra, B);
       }
     }
     pairs[2 * i] = p0;
@@ -365,7 +417,7 @@ __global__ void ag_ms_adjacency_kernel(const uint64_t* __restrict__ uniq, int64_
 template <int CAP>
 __global__ __launch_bounds__(64) void ag_ms_pairs_kernel(int64_t V, int x_hops, const int* __restrict__ deg,
                                                          const int* __restrict__ adj, const int32_t* __restrict__ rank,
-                                                         uint64_t* __restrict__ pairs) {
+                                                         int B, uint64_t* __restrict__ pairs) {
   const int64_t v = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (v >= V) return;
   int list[CAP];
@@ -398,20 +450,21 @@ __global__ __launch_bounds__(64) void ag_ms_pairs_kernel(int64_t V, int x_hops, 
   const int rv = rank[v];
   uint64_t* out = pairs + v * cap;
   for (int j = 0; j < cap; ++j) {
-    uint64_t key = AG_NO_PAIR;
+    uint64_t key = ag_no_pair(B);
     if (j < n && rv >= 0) {
       const int ru = rank[list[j]];
-      if (ru >= 0) key = ag_pair_key(rv, ru);
+      if (ru >= 0) key = ag_pair_key(rv, ru, B);
     }
     out[j] = key;
   }
 }
 
 // sorted pair keys -> 1 where a new distinct non-sentinel key starts
-__global__ void ag_ms_flag_unique_kernel(const uint64_t* __restrict__ sorted, int64_t n, int64_t* __restrict__ flags) {
+__global__ void ag_ms_flag_unique_kernel(const uint64_t* __restrict__ sorted, int64_t n, int B,
+                                         int64_t* __restrict__ flags) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     const uint64_t k = sorted[i];
-    flags[i] = (k != AG_NO_PAIR && (i == 0 || sorted[i - 1] != k)) ? 1 : 0;
+    flags[i] = (k != ag_no_pair(B) && (i == 0 || sorted[i - 1] != k)) ? 1 : 0;
   }
 }
 
@@ -420,14 +473,15 @@ __global__ void ag_ms_copy_total_kernel(const int64_t* __restrict__ offsets, int
 }
 
 __global__ void ag_ms_emit_kernel(const uint64_t* __restrict__ sorted, const int64_t* __restrict__ offsets, int64_t n,
-                                  int64_t num_edges, int32_t* __restrict__ out_src, int32_t* __restrict__ out_tgt) {
+                                  int B, int64_t num_edges, int32_t* __restrict__ out_src,
+                                  int32_t* __restrict__ out_tgt) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     const uint64_t k = sorted[i];
-    if (k != AG_NO_PAIR && (i == 0 || sorted[i - 1] != k)) {
+    if (k != ag_no_pair(B) && (i == 0 || sorted[i - 1] != k)) {
       const int64_t o = offsets[i];
       if (o < num_edges) {
-        out_src[o] = static_cast<int32_t>(static_cast<uint32_t>(k));
-        out_tgt[o] = static_cast<int32_t>(static_cast<uint32_t>(k >> 32));
+        out_src[o] = static_cast<int32_t>(k & ((uint64_t(1) << B) - 1));
+        out_tgt[o] = static_cast<int32_t>(k >> B);
       }
     }
   }
@@ -489,10 +543,10 @@ static int ag_ms_check(int R, const int32_t* levels, int nlevels, int x_hops) {
 }
 
 template <int CAP>
-static void ag_ms_launch_pairs(int64_t V, int x_hops, const AgMsWs& m, const int32_t* rank, uint64_t* pairs,
+static void ag_ms_launch_pairs(int64_t V, int x_hops, const AgMsWs& m, const int32_t* rank, int B, uint64_t* pairs,
                                hipStream_t s) {
   AG_KERNEL("ag_ms_pairs_kernel", ag_ms_pairs_kernel<CAP>, dim3(ag_blocks(V, 64)), dim3(64), s, V, x_hops, m.deg, m.adj,
-            rank, pairs);
+            rank, B, pairs);
 }
 
 extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, int x_hops, const int32_t* d_rank,
@@ -507,35 +561,49 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
   ag_ms_carve(c, R, levels, nlevels, x_hops, &m);
   if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_count: workspace too small");
   const int cap = ag_hops_capacity(x_hops);
+  const int B = ag_vertex_bits(R);
   int64_t slot_base = 0;
-  for (int i = 0; i < nlevels; ++i) {
-    const int l = levels[i];
-    const int64_t Eu = ag_ico_E(l), V = ag_ico_V(l);
-    const uint64_t* edges = d_level_edges + ag_ico_edge_offset(l);
-    uint64_t* pairs = m.pairs_a + slot_base;
-    if (x_hops == 1) {
-      AG_KERNEL("ag_ms_edge_pairs_kernel", ag_ms_edge_pairs_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, edges,
-                Eu, d_active, d_rank, pairs);
-      AG_LAUNCH_CHECK();
-    } else {
+  if (x_hops == 1) {
+    AgMsLevels lv;
+    lv.n = nlevels;
+    int64_t run = 0;
+    for (int i = 0; i < nlevels; ++i) {
+      lv.edge_off[i] = ag_ico_edge_offset(levels[i]);
+      run += ag_ico_E(levels[i]);
+      lv.end[i] = run;
+    }
+    for (int i = nlevels; i < AG_MS_MAX_LEVELS; ++i) {
+      lv.edge_off[i] = 0;
+      lv.end[i] = run;
+    }
+    AG_KERNEL("ag_ms_edge_pairs_kernel", ag_ms_edge_pairs_kernel, dim3(ag_blocks(run, 256, 8192)), dim3(256), s,
+              d_level_edges, lv, d_active, d_rank, B, m.pairs_a);
+    AG_LAUNCH_CHECK();
+    slot_base = 2 * run;
+  } else {
+    for (int i = 0; i < nlevels; ++i) {
+      const int l = levels[i];
+      const int64_t Eu = ag_ico_E(l), V = ag_ico_V(l);
+      const uint64_t* edges = d_level_edges + ag_ico_edge_offset(l);
+      uint64_t* pairs = m.pairs_a + slot_base;
       rc = ag_zero_i32(m.deg, V, s);
       if (rc) return rc;
       AG_KERNEL("ag_ms_adjacency_kernel", ag_ms_adjacency_kernel, dim3(ag_blocks(Eu, 256, 8192)), dim3(256), s, edges,
                 Eu, d_active, m.deg, m.adj);
       AG_LAUNCH_CHECK();
-      if (cap <= 18) ag_ms_launch_pairs<18>(V, x_hops, m, d_rank, pairs, s);
-      else if (cap <= 36) ag_ms_launch_pairs<36>(V, x_hops, m, d_rank, pairs, s);
-      else if (cap <= 90) ag_ms_launch_pairs<90>(V, x_hops, m, d_rank, pairs, s);
-      else ag_ms_launch_pairs<216>(V, x_hops, m, d_rank, pairs, s);
+      if (cap <= 18) ag_ms_launch_pairs<18>(V, x_hops, m, d_rank, B, pairs, s);
+      else if (cap <= 36) ag_ms_launch_pairs<36>(V, x_hops, m, d_rank, B, pairs, s);
+      else if (cap <= 90) ag_ms_launch_pairs<90>(V, x_hops, m, d_rank, B, pairs, s);
+      else ag_ms_launch_pairs<216>(V, x_hops, m, d_rank, B, pairs, s);
       AG_LAUNCH_CHECK();
+      slot_base += ag_ms_level_slots(l, x_hops);
     }
-    slot_base += ag_ms_level_slots(l, x_hops);
   }
   const int64_t n = slot_base;
-  rc = ag_sort_u64(m.temp, m.temp_bytes, m.pairs_a, m.pairs_b, n, 0, 64, s);
+  rc = ag_sort_u64(m.temp, m.temp_bytes, m.pairs_a, m.pairs_b, n, 0, 2 * B, s);
   if (rc) return rc;
   AG_KERNEL("ag_ms_flag_unique_kernel", ag_ms_flag_unique_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s, m.pairs_b,
-            n, m.offsets);
+            n, B, m.offsets);
   AG_LAUNCH_CHECK();
   rc = ag_exclusive_scan_i64(m.temp, m.temp_bytes, m.offsets, m.offsets, n, s);
   if (rc) return rc;
@@ -556,7 +624,7 @@ extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int
   ag_ms_carve(c, R, levels, nlevels, x_hops, &m);
   if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_fill: workspace too small");
   AG_KERNEL("ag_ms_emit_kernel", ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_b,
-            m.offsets, m.slots, num_edges, d_out_src, d_out_tgt);
+            m.offsets, m.slots, ag_vertex_bits(R), num_edges, d_out_src, d_out_tgt);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -141,6 +141,24 @@ int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t*
   return AG_OK;
 }
 
+size_t ag_sort_pairs_u64_i32_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  uint64_t* k = nullptr;
+  int32_t* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, static_cast<size_t>(n > 0 ? n : 1), 0u, 64u, hipStream_t(0));
+  return bytes + 256;
+}
+
+// stable ascending sort of (key, value) pairs on all 64 key bits
+int ag_sort_pairs_u64_i32(void* d_temp, size_t temp_bytes, const uint64_t* d_keys_in, uint64_t* d_keys_out,
+                          const int32_t* d_vals_in, int32_t* d_vals_out, int64_t n, hipStream_t stream) {
+  if (n <= 0) return AG_OK;
+  AgProfScope prof("rocprim_radix_sort_pairs", stream);
+  AG_HIP(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out,
+                                   static_cast<size_t>(n), 0u, 64u, stream));
+  return AG_OK;
+}
+
 size_t ag_scan_i32_temp_bytes(int64_t n) {
   size_t bytes = 0;
   int* p = nullptr;
