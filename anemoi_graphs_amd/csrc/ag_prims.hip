@@ -367,3 +367,22 @@ extern "C" int ag_unique_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int64_
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// target column of a fixed-degree edge list: out[r * k + j] = r
+// ---------------------------------------------------------------------------------------------
+__global__ void ag_fill_row_ids_kernel(int32_t* __restrict__ out, int64_t n, int k) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    out[i] = static_cast<int32_t>(i / k);
+}
+
+extern "C" int ag_fill_row_ids(int32_t* d_out, int64_t rows, int k, void* stream) {
+  AG_REQUIRE(rows >= 0 && k >= 1, "ag_fill_row_ids: bad sizes");
+  AG_REQUIRE(rows < (int64_t(1) << 31), "ag_fill_row_ids: row ids must fit int32");
+  if (rows == 0) return AG_OK;
+  AG_REQUIRE(d_out != nullptr, "ag_fill_row_ids: null pointer");
+  AG_KERNEL("ag_fill_row_ids_kernel", ag_fill_row_ids_kernel, dim3(ag_blocks(rows * k, 1024, 8192)), dim3(256),
+            static_cast<hipStream_t>(stream), d_out, rows * k, k);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}

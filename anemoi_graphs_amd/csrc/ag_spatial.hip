@@ -358,6 +358,59 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       bd[j] = 3.0e38f;
       bi[j] = -1;
     }
+    // Windows that fit one tile (the usual case) take the tagged path: the chord^2 bits with the
+    // low 8 mantissa bits replaced by the tile slot form a 32-bit key, and a sorted insert of a
+    // key is one v_min_u32 plus CAP-1 v_med3_u32, with no branch and no id bookkeeping; the ids are
+    // read back from the tile at the end.  The tag costs 255 ulp of resolution, which the
+    // classification below accounts for (ag_chord2_err_tagged).
+    int win_total = -1;
+    if (win.d[0] >= 0) {
+      win_total = 0;
+#pragma unroll
+      for (int r = 0; r < AG_WIN_RANGES; ++r)
+        if (r < win.d[0]) win_total += win.d[2 + 2 * r] - win.d[1 + 2 * r];
+    }
+    const bool tagged = win_total >= 0 && win_total <= AG_TILE;
+    if (tagged) {
+      int fillt = 0;
+#pragma unroll
+      for (int r = 0; r < AG_WIN_RANGES; ++r) {
+        if (r < win.d[0]) {
+          const int first_pos = win.d[1 + 2 * r], take = win.d[2 + 2 * r] - first_pos;
+          for (int i = lane; i < take; i += 64) tile[fillt + i] = a.spts[first_pos + i];
+          fillt += take;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      unsigned kb[CAP];
+#pragma unroll
+      for (int j = 0; j < CAP; ++j) kb[j] = 0xffffffffu;
+      for (int j = 0; j < fillt; ++j) {
+        const float4 s = tile[j];
+        const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
+        const float d = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+        const unsigned x = (__float_as_uint(d) & 0xffffff00u) | static_cast<unsigned>(j);
+        unsigned prev = kb[0];
+        kb[0] = min(prev, x);
+#pragma unroll
+        for (int i = 1; i < CAP; ++i) {
+          const unsigned cur = kb[i];
+          kb[i] = max(min(prev, cur), min(max(prev, cur), x));  // median of three
+          prev = cur;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CAP; ++j) {
+        if (kb[j] != 0xffffffffu) {
+          bd[j] = __uint_as_float(kb[j] & 0xffffff00u);
+          bi[j] = __float_as_int(tile[kb[j] & 0xffu].w);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     int fill = 0;
     auto scan_tile = [&](int count) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -385,7 +438,9 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
         }
       }
     };
-    if (win.d[0] >= 0) {
+    if (tagged) {
+      // done above
+    } else if (win.d[0] >= 0) {
 #pragma unroll
       for (int r = 0; r < AG_WIN_RANGES; ++r)
         if (r < win.d[0]) stage_run(win.d[1 + 2 * r], win.d[2 + 2 * r]);
@@ -415,7 +470,8 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
         dk = bd[j];
         ik = bi[j];
       }
-    const float ek = ag_chord2_err(dk);
+    auto err_of = [&](float c2) { return tagged ? ag_chord2_err_tagged(c2) : ag_chord2_err(c2); };
+    const float ek = err_of(dk);
     const float thr_hi = dk + 3.0f * ek + 4.0e-12f;
     const bool have_k = active && (ik >= 0);
     bool queued = active && !have_k;
@@ -430,7 +486,7 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       exact = (c1 != k - 1);
 #pragma unroll
       for (int j = 0; j + 1 < CAP; ++j)
-        if (j + 1 < k) exact = exact || ((bd[j + 1] - bd[j]) <= (ag_chord2_err(bd[j + 1]) + ag_chord2_err(bd[j])));
+        if (j + 1 < k) exact = exact || ((bd[j + 1] - bd[j]) <= (err_of(bd[j + 1]) + err_of(bd[j])));
       if (a.self_query) exact = true;  // the value of the 2nd smallest rdist is needed anyway
       if (!RESOLVE && exact) queued = true;
     }

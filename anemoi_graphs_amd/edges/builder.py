@@ -124,11 +124,7 @@ class KNNEdges(BaseEdgeBuilder, NodeMaskingMixin):
             self.num_nearest_neighbours, self.source_name, self.target_name,
         )
         k = self.num_nearest_neighbours
-        ids = ops.knn(source_coords, target_coords, k)  # [Nt, k], ascending distance
-        nt = target_coords.shape[0]
-        edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=ids.device)
-        edge_index[0] = ids.reshape(-1)
-        edge_index[1] = torch.arange(nt, dtype=torch.int32, device=ids.device).repeat_interleave(k)
+        edge_index = ops.knn_edges(source_coords, target_coords, k)  # per target: ascending distance
         return self.undo_masking(edge_index, source_nodes, target_nodes)
 
 

@@ -73,6 +73,27 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
     return res[0] if len(res) == 1 else res
 
 
+def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int) -> torch.Tensor:
+    """edge_index [2, Nt*k] int32 of the k-NN graph: row 0 the k nearest sources of every target
+    (ascending distance), row 1 the target id."""
+    lib = _lib.load()
+    dev = device_of(src, tgt)
+    src, tgt = coords(src, dev), coords(tgt, dev)
+    ns, nt = src.shape[0], tgt.shape[0]
+    if k > ns:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ns}")
+    with torch.cuda.device(dev):
+        edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=dev)
+        ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
+        _lib.check(
+            lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(edge_index[0]), None, None, _ptr(ws), ws.numel(),
+                       _stream(dev)),
+            "ag_knn",
+        )
+        _lib.check(lib.ag_fill_row_ids(_ptr(edge_index[1]), nt, k, _stream(dev)), "ag_fill_row_ids")
+    return edge_index
+
+
 def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
     """0-dim float64 device tensor: max over the nodes of the distance to the nearest other node."""
     lib = _lib.load()

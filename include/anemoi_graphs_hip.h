@@ -176,6 +176,11 @@ int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids, int64_t* d
 int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream);
 int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream);
 
+/* Target column of a fixed-degree edge list: d_out[r * k + j] = r for r < rows, j < k.
+ * Replaces the COO row array the reference takes from kneighbors_graph(...).tocoo()
+ * (edges/builder.py:80-84: edge_index row 1 = adjacency row = target id). */
+int ag_fill_row_ids(int32_t* d_out, int64_t rows, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
