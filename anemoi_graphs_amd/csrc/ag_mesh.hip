@@ -370,11 +370,14 @@ struct AgMsLevels {
   int64_t end[AG_MS_MAX_LEVELS];       // running total of edges over the selected levels
 };
 
-// x_hops == 1: both directions of every (active) mesh edge of every selected level, one fixed pair
-// of slots per edge (one launch for all levels)
+// x_hops == 1: both directions of every (active) mesh edge of every selected level (one launch
+// for all levels).  No pair can occur twice -- an edge of one level is split at the next -- so the
+// pairs only have to be grouped by target and ordered by source: every pair takes a slot in its
+// target's row here (one atomic counter per node), a prefix sum over the counters gives the row
+// offsets, the fill pass scatters the sources into their rows and sorts each short row.
 __global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ level_edges, AgMsLevels lv,
                                         const uint8_t* __restrict__ active, const int32_t* __restrict__ rank, int B,
-                                        uint64_t* __restrict__ pairs) {
+                                        uint64_t* __restrict__ pairs, int* __restrict__ slot, int* __restrict__ row_count) {
   const int64_t total = lv.end[lv.n - 1];
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
     int64_t start = 0, eoff = lv.edge_off[0];
@@ -388,15 +391,52 @@ __global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ level_edges
     const uint64_t k = level_edges[eoff + (i - start)];
     const int a = static_cast<int>(static_cast<uint32_t>(k)), b = static_cast<int>(static_cast<uint32_t>(k >> 32));
     uint64_t p0 = ag_no_pair(B), p1 = ag_no_pair(B);
+    int s0 = 0, s1 = 0;
     if (active == nullptr || (active[a] && active[b])) {
       const int ra = rank[a], rb = rank[b];
       if (ra >= 0 && rb >= 0) {
         p0 = ag_pair_key(ra, rb, B);
         p1 = ag_pair_key(rb, ra, B);
+        s0 = atomicAdd(&row_count[rb], 1);
+        s1 = atomicAdd(&row_count[ra], 1);
       }
     }
     pairs[2 * i] = p0;
     pairs[2 * i + 1] = p1;
+    slot[2 * i] = s0;
+    slot[2 * i + 1] = s1;
+  }
+}
+
+__global__ void ag_ms_total_i32_kernel(const int* __restrict__ offsets, int64_t n, int64_t* __restrict__ out) {
+  *out = offsets[n];
+}
+
+__global__ void ag_ms_scatter_kernel(const uint64_t* __restrict__ pairs, const int* __restrict__ slot, int64_t n, int B,
+                                     const int* __restrict__ row_start, int32_t* __restrict__ out_src,
+                                     int32_t* __restrict__ out_tgt) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const uint64_t k = pairs[i];
+    if (k == ag_no_pair(B)) continue;
+    const int src = static_cast<int>(k & ((uint64_t(1) << B) - 1)), tgt = static_cast<int>(k >> B);
+    const int64_t pos = int64_t(row_start[tgt]) + slot[i];
+    out_src[pos] = src;
+    out_tgt[pos] = tgt;
+  }
+}
+
+// one thread per edge: ascending sources inside every row.  Sources are distinct inside a row, so
+// the position of an entry is the number of smaller entries of its row (rows are short: at most
+// 6 per level).
+__global__ void ag_ms_row_rank_kernel(const int* __restrict__ row_start, const int32_t* __restrict__ unsorted,
+                                      const int32_t* __restrict__ out_tgt, int64_t E, int32_t* __restrict__ out_src) {
+  for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < E; e += int64_t(gridDim.x) * blockDim.x) {
+    const int t = out_tgt[e];
+    const int first = row_start[t], n = row_start[t + 1] - first;
+    const int32_t mine = unsorted[e];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (unsorted[first + j] < mine) ? 1 : 0;
+    out_src[first + r] = mine;
   }
 }
 
@@ -493,6 +533,9 @@ struct AgMsWs {
   uint64_t* pairs_a;  // [total slots]
   uint64_t* pairs_b;
   int64_t* offsets;   // [total slots + 1]
+  int* slot;          // [total slots]  position of a pair inside its target's row   (x_hops == 1)
+  int* row_start;     // [V_R + 1]      row counters, then row offsets               (x_hops == 1)
+  int32_t* unsorted;  // [total slots]  sources grouped by target, unsorted inside a row (x_hops == 1)
   void* temp;
   size_t temp_bytes;
   int64_t slots;
@@ -514,9 +557,16 @@ static int ag_ms_carve(AgCarver& c, int R, const int32_t* levels, int nlevels, i
   }
   m.slots = slots;
   m.pairs_a = c.take<uint64_t>(slots);
-  m.pairs_b = c.take<uint64_t>(slots);
-  m.offsets = c.take<int64_t>(slots + 1);
-  const size_t t1 = ag_sort_u64_temp_bytes(slots), t2 = ag_scan_i64_temp_bytes(slots);
+  m.pairs_b = x_hops > 1 ? c.take<uint64_t>(slots) : nullptr;
+  m.offsets = x_hops > 1 ? c.take<int64_t>(slots + 1) : nullptr;
+  m.slot = x_hops == 1 ? c.take<int>(slots) : nullptr;
+  m.row_start = x_hops == 1 ? c.take<int>(ag_ico_V(R) + 2) : nullptr;
+  m.unsorted = x_hops == 1 ? c.take<int32_t>(slots) : nullptr;
+  size_t t1 = ag_sort_u64_temp_bytes(slots), t2 = ag_scan_i64_temp_bytes(slots);
+  if (x_hops == 1) {
+    t1 = ag_scan_i32_temp_bytes(ag_ico_V(R) + 2);
+    t2 = 0;
+  }
   m.temp_bytes = t1 > t2 ? t1 : t2;
   m.temp = c.take<char>(m.temp_bytes);
   if (w) *w = m;
@@ -576,10 +626,17 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
       lv.edge_off[i] = 0;
       lv.end[i] = run;
     }
+    const int64_t V = ag_ico_V(R);
+    rc = ag_zero_i32(m.row_start, V + 1, s);
+    if (rc) return rc;
     AG_KERNEL("ag_ms_edge_pairs_kernel", ag_ms_edge_pairs_kernel, dim3(ag_blocks(run, 256, 8192)), dim3(256), s,
-              d_level_edges, lv, d_active, d_rank, B, m.pairs_a);
+              d_level_edges, lv, d_active, d_rank, B, m.pairs_a, m.slot, m.row_start);
     AG_LAUNCH_CHECK();
-    slot_base = 2 * run;
+    rc = ag_exclusive_scan_i32(m.temp, m.temp_bytes, m.row_start, m.row_start, V + 1, s);
+    if (rc) return rc;
+    AG_KERNEL("ag_ms_total_i32_kernel", ag_ms_total_i32_kernel, dim3(1), dim3(1), s, m.row_start, V, d_num_edges);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
   } else {
     for (int i = 0; i < nlevels; ++i) {
       const int l = levels[i];
@@ -623,6 +680,17 @@ extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int
   AgMsWs m;
   ag_ms_carve(c, R, levels, nlevels, x_hops, &m);
   if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_fill: workspace too small");
+  if (x_hops == 1) {
+    const int64_t V = ag_ico_V(R);
+    (void)V;
+    AG_KERNEL("ag_ms_scatter_kernel", ag_ms_scatter_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_a,
+              m.slot, m.slots, ag_vertex_bits(R), m.row_start, m.unsorted, d_out_tgt);
+    AG_LAUNCH_CHECK();
+    AG_KERNEL("ag_ms_row_rank_kernel", ag_ms_row_rank_kernel, dim3(ag_blocks(num_edges, 256, 8192)), dim3(256), s,
+              m.row_start, m.unsorted, d_out_tgt, num_edges, d_out_src);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+  }
   AG_KERNEL("ag_ms_emit_kernel", ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_b,
             m.offsets, m.slots, ag_vertex_bits(R), num_edges, d_out_src, d_out_tgt);
   AG_LAUNCH_CHECK();
