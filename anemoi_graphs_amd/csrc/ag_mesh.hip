@@ -197,18 +197,24 @@ __device__ __forceinline__ uint32_t ag_desc_key(float v) {
   return ~u;                                        // descending
 }
 
-// generate/transforms.py:50-52, plus the node-order sort input: position p holds vertex
-// id = V - 1 - p (descending ids, so that the stable sort breaks ties towards the larger id) with
-// key = (descending-latitude key << 32) | descending-longitude key
-__global__ void ag_ico_latlon_kernel(const double* __restrict__ xyz, int64_t V, float2* __restrict__ latlon,
-                                     uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
+// generate/transforms.py:50-52
+__global__ void ag_ico_latlon_kernel(const double* __restrict__ xyz, int64_t V, float2* __restrict__ latlon) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const double lat = asin(z / (x * x + y * y + z * z));
     const double lon = atan2(y, x);
-    const float2 p = make_float2(static_cast<float>(lat), static_cast<float>(lon));
-    latlon[i] = p;
-    const int64_t pos = V - 1 - i;
+    latlon[i] = make_float2(static_cast<float>(lat), static_cast<float>(lon));
+  }
+}
+
+// Node-order sort input (generate/utils.py:15-33): position p holds node id = n - 1 - p
+// (descending ids, so that the stable sort breaks ties towards the larger id) with
+// key = (descending-latitude key << 32) | descending-longitude key
+__global__ void ag_order_keys_kernel(const float2* __restrict__ latlon, int64_t n, uint64_t* __restrict__ keys,
+                                     int32_t* __restrict__ ids) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const float2 p = latlon[i];
+    const int64_t pos = n - 1 - i;
     keys[pos] = (static_cast<uint64_t>(ag_desc_key(p.x)) << 32) | ag_desc_key(p.y);
     ids[pos] = static_cast<int32_t>(i);
   }
@@ -276,6 +282,53 @@ static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, 
   return AG_OK;
 }
 
+// node order: latitude descending, ties longitude descending, ties node id descending -- one
+// stable sort of (latitude key, longitude key) pairs presented in descending id order
+static int ag_order_nodes(const float2* latlon, int64_t n, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_a,
+                          void* sort_temp, size_t sort_temp_bytes, int32_t* d_order, hipStream_t s) {
+  AG_KERNEL("ag_order_keys_kernel", ag_order_keys_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s, latlon, n, keys_a,
+            ids_a);
+  AG_LAUNCH_CHECK();
+  return ag_sort_pairs_u64_i32(sort_temp, sort_temp_bytes, keys_a, keys_b, ids_a, d_order, n, s);
+}
+
+static void ag_node_order_carve(AgCarver& c, int64_t n, uint64_t** ka, uint64_t** kb, int32_t** ids, void** temp,
+                                size_t* temp_bytes) {
+  uint64_t* a = c.take<uint64_t>(n);
+  uint64_t* b = c.take<uint64_t>(n);
+  int32_t* i = c.take<int32_t>(n);
+  const size_t tb = ag_sort_pairs_u64_i32_temp_bytes(n);
+  void* t = c.take<char>(tb);
+  if (ka) *ka = a;
+  if (kb) *kb = b;
+  if (ids) *ids = i;
+  if (temp) *temp = t;
+  if (temp_bytes) *temp_bytes = tb;
+}
+
+extern "C" size_t ag_node_order_workspace_bytes(int64_t n) {
+  if (n < 1) return 0;
+  AgCarver c(nullptr);
+  ag_node_order_carve(c, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return c.total();
+}
+
+extern "C" int ag_node_order(const float* d_latlon, int64_t n, int32_t* d_order, void* d_ws, size_t ws_bytes,
+                             void* stream) {
+  AG_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "ag_node_order: node count must fit int32");
+  if (n == 0) return AG_OK;
+  AG_REQUIRE(d_latlon && d_order && d_ws, "ag_node_order: null pointer");
+  if (ws_bytes < ag_node_order_workspace_bytes(n)) return ag_fail(AG_ERR_WORKSPACE, "ag_node_order: workspace too small");
+  AgCarver c(d_ws);
+  uint64_t *ka, *kb;
+  int32_t* ids;
+  void* temp;
+  size_t temp_bytes;
+  ag_node_order_carve(c, n, &ka, &kb, &ids, &temp, &temp_bytes);
+  return ag_order_nodes(reinterpret_cast<const float2*>(d_latlon), n, ka, kb, ids, temp, temp_bytes, d_order,
+                        static_cast<hipStream_t>(stream));
+}
+
 extern "C" int ag_icosphere_sizes(int R, int64_t* V, int64_t* F, int64_t* E_all) {
   AG_REQUIRE(R >= 0 && R <= AG_ICO_MAX_LEVEL, "ag_icosphere: resolution %d outside [0, %d]", R, AG_ICO_MAX_LEVEL);
   if (V) *V = ag_ico_V(R);
@@ -338,11 +391,9 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   }
   const int64_t V = ag_ico_V(R);
   const int vb = ag_blocks(V, 256, 8192);
-  AG_KERNEL("ag_ico_latlon_kernel", ag_ico_latlon_kernel, dim3(vb), dim3(256), s, d_xyz, V, latlon, w.keys_a, w.ids_a);
+  AG_KERNEL("ag_ico_latlon_kernel", ag_ico_latlon_kernel, dim3(vb), dim3(256), s, d_xyz, V, latlon);
   AG_LAUNCH_CHECK();
-  // node order: latitude descending, ties longitude descending, ties vertex id descending -- one
-  // stable sort of (latitude key, longitude key) pairs presented in descending id order
-  rc = ag_sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.ids_a, d_order, V, s);
+  rc = ag_order_nodes(latlon, V, w.keys_a, w.keys_b, w.ids_a, w.sort_temp, w.sort_temp_bytes, d_order, s);
   if (rc) return rc;
   AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, d_order, latlon, V,
             reinterpret_cast<float2*>(d_latlon), d_rank);

@@ -170,7 +170,7 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
 class MultiScaleEdges(BaseEdgeBuilder):
     """Multi-scale edges between the nodes of a refined icosahedron (edges/builder.py:374-462)."""
 
-    VALID_NODES = ["TriNodes"]
+    VALID_NODES = ["TriNodes", "LimitedAreaTriNodes", "StretchedTriNodes"]
 
     def __init__(self, source_name: str, target_name: str, x_hops: int, **kwargs):
         super().__init__(source_name, target_name)
@@ -184,7 +184,11 @@ class MultiScaleEdges(BaseEdgeBuilder):
             raise ValueError(f"Invalid node type {source_nodes.node_type}")
         mesh = source_nodes["_nx_graph"]
         resolutions = list(source_nodes["_resolutions"])
-        return ops.multiscale_edges(mesh.resolution, resolutions, self.x_hops, mesh.rank, mesh.level_edges)
+        # LimitedAreaTriNodes / StretchedTriNodes: only mesh vertices that are nodes take part, at every
+        # level (generate/tri_icosahedron.py:176-183 with the builder's area mask, respectively the
+        # 1 km "is a node" mask of edges/builder.py:422-432)
+        return ops.multiscale_edges(mesh.resolution, resolutions, self.x_hops, mesh.rank, mesh.level_edges,
+                                    getattr(mesh, "active", None))
 
     def update_graph(self, graph: HeteroData, attrs_config: dict | None = None) -> HeteroData:
         node_type = graph[self.source_name].node_type

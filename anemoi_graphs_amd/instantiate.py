@@ -9,6 +9,8 @@ import importlib
 
 _ALIASES = {
     "anemoi.graphs.nodes.TriNodes": "anemoi_graphs_amd.nodes.TriNodes",
+    "anemoi.graphs.nodes.LimitedAreaTriNodes": "anemoi_graphs_amd.nodes.LimitedAreaTriNodes",
+    "anemoi.graphs.nodes.StretchedTriNodes": "anemoi_graphs_amd.nodes.StretchedTriNodes",
     "anemoi.graphs.nodes.LatLonNodes": "anemoi_graphs_amd.nodes.LatLonNodes",
     "anemoi.graphs.edges.KNNEdges": "anemoi_graphs_amd.edges.KNNEdges",
     "anemoi.graphs.edges.CutOffEdges": "anemoi_graphs_amd.edges.CutOffEdges",

@@ -1,3 +1,10 @@
-from .builders import BaseNodeBuilder, IcosahedralNodes, LatLonNodes, TriNodes
+from .builders import (
+    BaseNodeBuilder,
+    IcosahedralNodes,
+    LatLonNodes,
+    LimitedAreaTriNodes,
+    StretchedTriNodes,
+    TriNodes,
+)
 
-__all__ = ["BaseNodeBuilder", "IcosahedralNodes", "TriNodes", "LatLonNodes"]
+__all__ = ["BaseNodeBuilder", "IcosahedralNodes", "TriNodes", "LimitedAreaTriNodes", "StretchedTriNodes", "LatLonNodes"]

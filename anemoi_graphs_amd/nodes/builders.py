@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from .. import ops, settings
+from ..generate.masks import KNNAreaMaskBuilder
 from ..hetero import HeteroData
 from ..instantiate import instantiate
 
@@ -74,11 +75,13 @@ class IcosahedralMesh:
     here the device-side description of the icosphere -- node<->vertex permutations -- instead of a
     networkx graph.  ``number_of_nodes`` and ``nodes`` keep the two accessors callers use."""
 
-    def __init__(self, resolution: int, order: torch.Tensor, rank: torch.Tensor, level_edges: torch.Tensor):
+    def __init__(self, resolution: int, order: torch.Tensor, rank: torch.Tensor, level_edges: torch.Tensor,
+                 active: torch.Tensor | None = None):
         self.resolution = resolution
-        self.order = order  # node -> vertex (int32, device)
-        self.rank = rank    # vertex -> node (int32, device)
+        self.order = order  # node -> id of the node in the builder's unsorted coordinate array (int32, device)
+        self.rank = rank    # mesh vertex -> node position, -1 for vertices that are not nodes (int32, device)
         self.level_edges = level_edges  # unique mesh edges of every refinement level (int64 keys, device)
+        self.active = active  # uint8 per mesh vertex: 1 where the vertex is a node (None: all)
 
     def number_of_nodes(self) -> int:
         return int(self.order.numel())
@@ -120,3 +123,85 @@ class TriNodes(IcosahedralNodes):
         mesh = IcosahedralMesh(resolution, order, rank, level_edges)
         coords = latlon if settings.device_resident else latlon.cpu()
         return mesh, coords, order.cpu().tolist() if not settings.device_resident else order
+
+
+def _finish(mesh, coords, order):
+    if settings.device_resident:
+        return mesh, coords, order
+    return mesh, coords.cpu(), order.cpu().tolist()
+
+
+class LimitedAreaIcosahedralNodes(IcosahedralNodes, ABC):
+    """Icosahedral nodes restricted to an area of interest (from_refined_icosahedron.py:72-96)."""
+
+    def __init__(self, resolution: int | list[int], reference_node_name: str, name: str,
+                 mask_attr_name: str | None = None, margin_radius_km: float = 100.0) -> None:
+        super().__init__(resolution, name)
+        self.area_mask_builder = KNNAreaMaskBuilder(reference_node_name, margin_radius_km, mask_attr_name)
+
+    def register_nodes(self, graph: HeteroData) -> HeteroData:
+        self.area_mask_builder.fit(graph)
+        return super().register_nodes(graph)
+
+
+class LimitedAreaTriNodes(LimitedAreaIcosahedralNodes):
+    """Icosphere nodes within ``margin_radius_km`` of the reference nodes
+    (from_refined_icosahedron.py:119-131 -> generate/tri_icosahedron.py:47-58): the order is the
+    global TriNodes order restricted to the masked vertices."""
+
+    def create_nodes(self):
+        resolution = max(self.resolutions)
+        _xyz, _faces, latlon, order, _rank, level_edges = ops.icosphere(resolution)
+        keep = self.area_mask_builder.get_mask(latlon)  # in node order
+        coords = latlon[keep].contiguous()
+        node_ordering = order[keep].contiguous()
+        rank = torch.full((order.numel(),), -1, dtype=torch.int32, device=order.device)
+        rank[node_ordering.long()] = torch.arange(node_ordering.numel(), dtype=torch.int32, device=order.device)
+        mesh = IcosahedralMesh(resolution, node_ordering, rank, level_edges, (rank >= 0).to(torch.uint8))
+        return _finish(mesh, coords, node_ordering)
+
+
+class StretchedIcosahedronNodes(IcosahedralNodes, ABC):
+    """Icosahedral nodes at two resolutions (from_refined_icosahedron.py:149-176)."""
+
+    def __init__(self, global_resolution: int, lam_resolution: int, name: str, reference_node_name: str,
+                 mask_attr_name: str, margin_radius_km: float = 100.0) -> None:
+        super().__init__(lam_resolution, name)
+        self.global_resolution = global_resolution
+        self.area_mask_builder = KNNAreaMaskBuilder(reference_node_name, margin_radius_km, mask_attr_name)
+
+    def register_nodes(self, graph: HeteroData) -> HeteroData:
+        self.area_mask_builder.fit(graph)
+        return super().register_nodes(graph)
+
+
+class StretchedTriNodes(StretchedIcosahedronNodes):
+    """Icosphere nodes of ``global_resolution`` outside the area of interest plus those of
+    ``lam_resolution`` inside it (from_refined_icosahedron.py:179-191 ->
+    generate/tri_icosahedron.py:61-105).  Node ids index the concatenation [coarse outside, fine
+    inside]; the node order is latitude descending over that concatenation."""
+
+    def create_nodes(self):
+        lam_resolution = max(self.resolutions)
+        _x, _f, base_sorted, _o, base_rank, _e = ops.icosphere(self.global_resolution)
+        _x, _f, lam_sorted, _o, lam_rank, level_edges = ops.icosphere(lam_resolution)
+        base = base_sorted[base_rank.long()]  # vertex order
+        lam = lam_sorted[lam_rank.long()]
+        base_out = ~self.area_mask_builder.get_mask(base)
+        lam_in = self.area_mask_builder.get_mask(lam)
+        coords_all = torch.cat([base[base_out], lam[lam_in]]).contiguous()
+        node_ordering = ops.node_order(coords_all)
+        coords = coords_all[node_ordering.long()].contiguous()
+        dev = lam.device
+        n_base = int(base_out.sum().item())
+        # mesh vertex -> id in the concatenation (coarse vertices are the first vertices of the fine mesh)
+        cid = torch.full((lam.shape[0],), -1, dtype=torch.int64, device=dev)
+        cid[torch.nonzero(base_out).squeeze(1)] = torch.arange(n_base, device=dev)
+        idx_l = torch.nonzero(lam_in).squeeze(1)
+        cid[idx_l] = n_base + torch.arange(idx_l.numel(), device=dev)
+        position = torch.empty(coords_all.shape[0], dtype=torch.int32, device=dev)
+        position[node_ordering.long()] = torch.arange(coords_all.shape[0], dtype=torch.int32, device=dev)
+        rank = torch.where(cid >= 0, position[cid.clamp(min=0)], torch.full_like(position[:1], -1).expand(cid.numel()))
+        rank = rank.to(torch.int32).contiguous()
+        mesh = IcosahedralMesh(lam_resolution, node_ordering, rank, level_edges, (rank >= 0).to(torch.uint8))
+        return _finish(mesh, coords, node_ordering)

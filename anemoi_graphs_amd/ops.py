@@ -225,6 +225,20 @@ def icosphere(resolution: int, device: torch.device | None = None):
     return xyz, faces, latlon, order, rank, level_edges
 
 
+def node_order(latlon: torch.Tensor) -> torch.Tensor:
+    """int32 [N] permutation that orders nodes by latitude descending (ties: longitude descending,
+    then id descending)."""
+    lib = _lib.load()
+    dev = device_of(latlon)
+    latlon = coords(latlon, dev)
+    n = latlon.shape[0]
+    with torch.cuda.device(dev):
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        ws = _workspace(lib.ag_node_order_workspace_bytes(n), dev)
+        _lib.check(lib.ag_node_order(_ptr(latlon), n, _ptr(order), _ptr(ws), ws.numel(), _stream(dev)), "ag_node_order")
+    return order
+
+
 def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: torch.Tensor,
                      level_edges: torch.Tensor, active: torch.Tensor | None = None) -> torch.Tensor:
     """edge_index [2,E] int32 of the multi-scale icosahedral edges, sorted by (target, source)."""

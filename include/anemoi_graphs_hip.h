@@ -111,6 +111,12 @@ size_t ag_icosphere_workspace_bytes(int R);
 int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_t* d_order, int32_t* d_rank,
                  uint64_t* d_level_edges, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Node order of a set of (lat, lon) float32 coordinates: latitude descending, ties longitude
+ * descending, ties node id descending -- what get_coordinates_ordering (generate/utils.py:15-33)
+ * yields when its two argsorts are stable.  d_order[i] = id of the node at position i. */
+size_t ag_node_order_workspace_bytes(int64_t n);
+int ag_node_order(const float* d_latlon, int64_t n, int32_t* d_order, void* d_ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Multi-scale icosahedral edges.
  * Replaces tri_icosahedron.add_edges_to_nx_graph (generate/tri_icosahedron.py:165-188) and

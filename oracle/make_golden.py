@@ -164,6 +164,38 @@ def case_tri(ref):
     return out
 
 
+def _area_nodes():
+    """A regional 0.5-degree patch (lat 35..60, lon -10..30 degrees) as the reference nodes of the area masks."""
+    lat = np.arange(60.0, 34.9, -0.5)
+    lon = np.arange(-10.0, 30.1, 0.5)
+    la, lo = np.meshgrid(lat, lon, indexing="ij")
+    return np.deg2rad(np.stack([la.ravel(), lo.ravel()], axis=1)).astype(np.float32)
+
+
+def case_lam(ref):
+    """LimitedAreaTriNodes / StretchedTriNodes with MultiScaleEdges through the reference's classes
+    (on this repository's icosphere)."""
+    area = _area_nodes()
+    out = {"area": area, "parity_unpinned_geometry": np.int32(1)}
+    for r, hops, margin in ((4, 1, 100.0), (5, 1, 400.0), (4, 2, 300.0)):
+        g = _graph(ref, area=area)
+        g = ref.LimitedAreaTriNodes(r, "area", "h", margin_radius_km=margin).update_graph(g, {})
+        g = ref.MultiScaleEdges("h", "h", hops).update_graph(g)
+        tag = f"lam_r{r}_h{hops}"
+        out[f"{tag}_margin"] = np.float64(margin)
+        out[f"{tag}_x"] = g["h"].x.numpy()
+        out[f"{tag}_edge_index"] = g[("h", "to", "h")].edge_index.numpy()
+    for rb, rl, hops, margin in ((2, 4, 1, 100.0), (1, 4, 1, 500.0), (2, 4, 2, 200.0)):
+        g = _graph(ref, area=area)
+        g = ref.StretchedTriNodes(rb, rl, "h", "area", None, margin_radius_km=margin).update_graph(g, {})
+        g = ref.MultiScaleEdges("h", "h", hops).update_graph(g)
+        tag = f"stretched_r{rb}_{rl}_h{hops}"
+        out[f"{tag}_margin"] = np.float64(margin)
+        out[f"{tag}_x"] = g["h"].x.numpy()
+        out[f"{tag}_edge_index"] = g[("h", "to", "h")].edge_index.numpy()
+    return out
+
+
 def case_concat(ref):
     """/root/reference/tests/test_utils.py:7-18 plus a random case."""
     e1 = torch.tensor([[0, 1, 2, 3], [-1, -2, -3, -4]])
@@ -189,8 +221,12 @@ def main() -> None:
         "o96_tri4": case_o96_tri4,
         "tri_multiscale": case_tri,
         "concat_edges": case_concat,
+        "lam_stretched": case_lam,
     }
+    only = set(sys.argv[1:])
     for name, fn in cases.items():
+        if only and name not in only:
+            continue
         data = fn(ref)
         np.savez_compressed(OUT / f"{name}.npz", **data)
         print(name, {k: getattr(v, "shape", v) for k, v in data.items()})

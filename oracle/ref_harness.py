@@ -175,12 +175,13 @@ def reference():
     ns.DotDict = DotDict
     from anemoi.graphs.edges.builder import CutOffEdges, KNNEdges, MultiScaleEdges
     from anemoi.graphs.edges.attributes import EdgeDirection, EdgeLength
-    from anemoi.graphs.nodes.builders.from_refined_icosahedron import TriNodes
+    from anemoi.graphs.nodes.builders.from_refined_icosahedron import LimitedAreaTriNodes, StretchedTriNodes, TriNodes
     from anemoi.graphs.utils import concat_edges, get_grid_reference_distance, haversine_distance
     from anemoi.graphs.generate.utils import get_coordinates_ordering
 
     ns.KNNEdges, ns.CutOffEdges, ns.MultiScaleEdges = KNNEdges, CutOffEdges, MultiScaleEdges
     ns.EdgeLength, ns.EdgeDirection, ns.TriNodes = EdgeLength, EdgeDirection, TriNodes
+    ns.LimitedAreaTriNodes, ns.StretchedTriNodes = LimitedAreaTriNodes, StretchedTriNodes
     ns.concat_edges = concat_edges
     ns.get_grid_reference_distance = get_grid_reference_distance
     ns.haversine_distance = haversine_distance

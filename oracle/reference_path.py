@@ -200,10 +200,53 @@ def tri_nodes(resolution: int, canonical: bool = True):
     return coords[order], order
 
 
-def multiscale_edges(resolutions: list[int], x_hops: int, node_ordering: np.ndarray) -> np.ndarray:
+EARTH_RADIUS = 6371.0  # km, anemoi/graphs/__init__.py
+
+
+def area_mask(reference_coords: np.ndarray, coords: np.ndarray, margin_radius_km: float) -> np.ndarray:
+    """KNNAreaMaskBuilder.fit_coords + get_mask (generate/masks.py:72-99)."""
+    nn = _nearest_neighbors(np.asarray(reference_coords))
+    dists, _ = nn.kneighbors(np.asarray(coords), n_neighbors=1)
+    return dists[:, 0] * EARTH_RADIUS <= margin_radius_km
+
+
+def limited_area_tri_nodes(resolution: int, reference_coords: np.ndarray, margin_radius_km: float):
+    """create_tri_nodes with an area mask (generate/tri_icosahedron.py:47-58), canonical order
+    -> (x float32 [n,2], node_ordering = vertex ids, all float64 vertex coordinates)."""
+    from . import icosphere as ico
+
+    coords = ico.latlon_rad(ico.icosphere(resolution)[0])
+    order = coordinates_ordering_canonical(coords)
+    mask = area_mask(reference_coords, coords, margin_radius_km)
+    order = order[mask[order]]
+    return coords[order].astype(np.float32), order, coords
+
+
+def stretched_tri_nodes(base_resolution: int, lam_resolution: int, reference_coords: np.ndarray,
+                        margin_radius_km: float):
+    """create_stretched_tri_nodes (generate/tri_icosahedron.py:89-105), canonical order
+    -> (x float32 [n,2], node_ordering = ids into the concatenated coordinates, those coordinates)."""
+    from . import icosphere as ico
+
+    base = ico.latlon_rad(ico.icosphere(base_resolution)[0])
+    lam = ico.latlon_rad(ico.icosphere(lam_resolution)[0])
+    base_out = ~area_mask(reference_coords, base, margin_radius_km)
+    lam_in = area_mask(reference_coords, lam, margin_radius_km)
+    coords = np.concatenate([base[base_out], lam[lam_in]])
+    order = coordinates_ordering_canonical(coords)
+    return coords[order].astype(np.float32), order, coords
+
+
+def multiscale_edges(resolutions: list[int], x_hops: int, node_ordering: np.ndarray, node_coords: np.ndarray | None = None,
+                     mask_reference: np.ndarray | None = None, margin_radius_km: float = 100.0) -> np.ndarray:
     """add_edges_to_nx_graph (generate/tri_icosahedron.py:165-188), get_neighbours_within_hops
     (:212-224), create_node_neighbours_list (:298-310) and MultiScaleEdges.get_adjacency_matrix
     (edges/builder.py:453) restated with networkx, as the reference uses it.
+
+    ``node_coords``: float64 coordinates indexed by node id (default: the vertices of the finest
+    icosphere, the TriNodes case).  ``mask_reference``/``margin_radius_km``: the area mask applied to
+    the vertices of every level (LimitedAreaTriNodes: the builder's reference nodes and margin;
+    StretchedTriNodes: the graph's own float32 node coordinates with 1 km, edges/builder.py:422-432).
 
     Returns int32 [2,E]; node ids are positions in ``node_ordering`` (the graph's insertion
     order, edges/builder.py:453 ``nx.to_scipy_sparse_array``)."""
@@ -212,20 +255,25 @@ def multiscale_edges(resolutions: list[int], x_hops: int, node_ordering: np.ndar
 
     from . import icosphere as ico
 
-    final_v, _ = ico.icosphere(max(resolutions))
-    final_coords = ico.latlon_rad(final_v)
+    if node_coords is None:
+        node_coords = ico.latlon_rad(ico.icosphere(max(resolutions))[0])
     graph = nx.DiGraph()
     for node_id in node_ordering:
         graph.add_node(int(node_id))
     sorted_nodes = sorted(graph.nodes)
-    tree = BallTree(final_coords[sorted_nodes], metric="haversine")
+    tree = BallTree(node_coords[sorted_nodes], metric="haversine")
     for resolution in resolutions:
         v, f = ico.icosphere(resolution)
         r_coords = ico.latlon_rad(v)
         edges = np.unique(ico.face_edges(f), axis=0)
+        if mask_reference is not None:
+            valid = np.where(area_mask(mask_reference, r_coords, margin_radius_km))[0]
+            edges = edges[np.isin(edges, valid).all(axis=1)]
+        else:
+            valid = range(len(v))
         mesh = nx.from_edgelist(edges)
         neighbours = {
-            i: set(nx.ego_graph(mesh, i, radius=x_hops, center=False) if i in mesh else []) for i in range(len(v))
+            int(i): set(nx.ego_graph(mesh, i, radius=x_hops, center=False) if i in mesh else []) for i in valid
         }
         _, mapping = tree.query(r_coords, k=1)
         pairs = [

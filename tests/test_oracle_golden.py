@@ -81,6 +81,44 @@ def test_tri_nodes_and_multiscale(golden, r, hops):
     assert np.array_equal(h.canonical(e), h.canonical(want))
 
 
+def _same_nodes(x, ref_x):
+    assert x.shape == ref_x.shape
+    assert np.array_equal(x[np.lexsort((x[:, 1], x[:, 0]))], ref_x[np.lexsort((ref_x[:, 1], ref_x[:, 0]))])
+    assert np.array_equal(ref_x[:, 0], x[:, 0])  # latitudes descend identically
+
+
+@pytest.mark.parametrize("r,hops", [(4, 1), (5, 1), (4, 2)])
+def test_limited_area_tri_nodes(golden, r, hops):
+    """LimitedAreaTriNodes + MultiScaleEdges of the reference (from_refined_icosahedron.py:119-131,
+    generate/tri_icosahedron.py:47-58,165-188) against the restatement."""
+    g = golden("lam_stretched")
+    tag = f"lam_r{r}_h{hops}"
+    margin = float(g[f"{tag}_margin"])
+    x, order, coords = rp.limited_area_tri_nodes(r, g["area"], margin)
+    ref_x = g[f"{tag}_x"]
+    _same_nodes(x, ref_x)
+    e = rp.multiscale_edges(list(range(r + 1)), hops, order, node_coords=coords, mask_reference=g["area"],
+                            margin_radius_km=margin)
+    want = _relabel(ref_x, g[f"{tag}_edge_index"], x)
+    assert np.array_equal(h.canonical(e), h.canonical(want))
+
+
+@pytest.mark.parametrize("rb,rl,hops", [(2, 4, 1), (1, 4, 1), (2, 4, 2)])
+def test_stretched_tri_nodes(golden, rb, rl, hops):
+    """StretchedTriNodes + MultiScaleEdges of the reference (from_refined_icosahedron.py:179-191,
+    generate/tri_icosahedron.py:89-105, edges/builder.py:422-432) against the restatement."""
+    g = golden("lam_stretched")
+    tag = f"stretched_r{rb}_{rl}_h{hops}"
+    margin = float(g[f"{tag}_margin"])
+    x, order, coords = rp.stretched_tri_nodes(rb, rl, g["area"], margin)
+    ref_x = g[f"{tag}_x"]
+    _same_nodes(x, ref_x)
+    e = rp.multiscale_edges(list(range(rl + 1)), hops, order, node_coords=coords, mask_reference=x,
+                            margin_radius_km=1.0)
+    want = _relabel(ref_x, g[f"{tag}_edge_index"], x)
+    assert np.array_equal(h.canonical(e), h.canonical(want))
+
+
 def test_reference_ordering_restated(golden):
     g = golden("tri_multiscale")
     from oracle import icosphere as ico
