@@ -386,3 +386,40 @@ extern "C" int ag_fill_row_ids(int32_t* d_out, int64_t rows, int k, void* stream
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// connected-node masks and index compaction maps (processors/post_process.py:48-61,133-149)
+// ---------------------------------------------------------------------------------------------
+__global__ void ag_mark_ids_kernel(const int32_t* __restrict__ ids, int64_t n, uint8_t* __restrict__ mask, int64_t n_mask,
+                                   int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int32_t v = ids[i];
+    if (v >= 0 && v < n_mask) mask[v] = 1;  // every writer stores the same byte
+    else if (bad != nullptr) *bad = 1;
+  }
+}
+
+extern "C" int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, void* stream) {
+  AG_REQUIRE(n >= 0 && n_mask >= 0, "ag_mark_ids: negative size");
+  if (n == 0) return AG_OK;
+  AG_REQUIRE(d_ids && d_mask, "ag_mark_ids: null pointer");
+  AG_KERNEL("ag_mark_ids_kernel", ag_mark_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256),
+            static_cast<hipStream_t>(stream), d_ids, n, d_mask, n_mask, static_cast<int*>(nullptr));
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+__global__ void ag_invert_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int32_t* __restrict__ map) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    map[ids[i]] = static_cast<int32_t>(i);
+}
+
+extern "C" int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, void* stream) {
+  AG_REQUIRE(n >= 0, "ag_invert_ids: negative size");
+  if (n == 0) return AG_OK;
+  AG_REQUIRE(d_ids && d_map, "ag_invert_ids: null pointer");
+  AG_KERNEL("ag_invert_ids_kernel", ag_invert_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256),
+            static_cast<hipStream_t>(stream), d_ids, n, d_map);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}

@@ -28,7 +28,11 @@ except ImportError:
             del self[key]
 
         def node_attrs(self):
-            return list(self.keys())
+            """Names of the per-node tensors (first dimension = number of nodes)."""
+            if "x" not in self:
+                return [k for k, v in self.items() if hasattr(v, "shape")]
+            n = self["x"].shape[0]
+            return [k for k, v in self.items() if hasattr(v, "shape") and len(v.shape) > 0 and v.shape[0] == n]
 
         @property
         def num_nodes(self):
@@ -57,6 +61,12 @@ except ImportError:
         @property
         def edge_types(self):
             return [k for k, v in self._stores.items() if isinstance(k, tuple)]
+
+        def edge_items(self):
+            return [(k, v) for k, v in self._stores.items() if isinstance(k, tuple)]
+
+        def node_items(self):
+            return [(k, v) for k, v in self._stores.items() if isinstance(k, str)]
 
         def __repr__(self):
             def shape(v):

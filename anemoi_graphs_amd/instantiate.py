@@ -15,6 +15,7 @@ _ALIASES = {
     "anemoi.graphs.edges.KNNEdges": "anemoi_graphs_amd.edges.KNNEdges",
     "anemoi.graphs.edges.CutOffEdges": "anemoi_graphs_amd.edges.CutOffEdges",
     "anemoi.graphs.edges.MultiScaleEdges": "anemoi_graphs_amd.edges.MultiScaleEdges",
+    "anemoi.graphs.processors.RemoveUnconnectedNodes": "anemoi_graphs_amd.processors.RemoveUnconnectedNodes",
     "anemoi.graphs.edges.attributes.EdgeLength": "anemoi_graphs_amd.edges.attributes.EdgeLength",
     "anemoi.graphs.edges.attributes.EdgeDirection": "anemoi_graphs_amd.edges.attributes.EdgeDirection",
 }

@@ -200,6 +200,27 @@ def remap_ids_(values: torch.Tensor, id_map: torch.Tensor) -> torch.Tensor:
     return values
 
 
+def mark_ids_(mask: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """mask[ids] = 1 in place (uint8 device mask, int32 device ids)."""
+    lib = _lib.load()
+    dev = mask.device
+    assert mask.dtype == torch.uint8 and mask.is_contiguous()
+    ids = ids.to(device=dev, dtype=torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ag_mark_ids(_ptr(ids), ids.numel(), _ptr(mask), mask.numel(), _stream(dev)), "ag_mark_ids")
+    return mask
+
+
+def invert_ids(ids: torch.Tensor, size: int) -> torch.Tensor:
+    """int32 [size] map with map[ids[j]] = j and -1 elsewhere."""
+    lib = _lib.load()
+    dev = ids.device
+    with torch.cuda.device(dev):
+        out = torch.full((size,), -1, dtype=torch.int32, device=dev)
+        _lib.check(lib.ag_invert_ids(_ptr(ids), ids.numel(), _ptr(out), _stream(dev)), "ag_invert_ids")
+    return out
+
+
 def icosphere(resolution: int, device: torch.device | None = None):
     """(xyz float64 [V,3], faces int32 [F,3], latlon float32 [V,2] in node order, order int32 [V],
     rank int32 [V], level_edges int64 [E_all] = unique mesh edges of every level 0..resolution)."""

@@ -182,6 +182,14 @@ int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids, int64_t* d
 int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream);
 int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream);
 
+/* Post-processing of node sets (processors/post_process.py:48-61,133-149).
+ * ag_mark_ids: d_mask[d_ids[i]] = 1 for every i (the mask of nodes that occur in an edge list;
+ *   replaces connected_mask[edges.edge_index[r]] = True, :142-147).
+ * ag_invert_ids: d_map[d_ids[j]] = j (old id -> new id for the ids kept by ag_mask_compact; with
+ *   ag_remap_ids this replaces the per-edge Python dict lookup of update_edge_indices, :51-61). */
+int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, void* stream);
+int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, void* stream);
+
 /* Target column of a fixed-degree edge list: d_out[r * k + j] = r for r < rows, j < k.
  * Replaces the COO row array the reference takes from kneighbors_graph(...).tocoo()
  * (edges/builder.py:80-84: edge_index row 1 = adjacency row = target id). */
