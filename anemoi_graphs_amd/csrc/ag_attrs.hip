@@ -271,32 +271,53 @@ __device__ __forceinline__ double ag_wave_max(double v) {
   return v;
 }
 
+// number of leading floats before the first 16-byte boundary of v (at most n)
+__device__ __forceinline__ int64_t ag_align_head(const float* v, int64_t n) {
+  const int64_t h = static_cast<int64_t>(((16 - (reinterpret_cast<uintptr_t>(v) & 15)) & 15) >> 2);
+  return h < n ? h : n;
+}
+
 // pass 0: sum, sum of squares, min, max.  pass 1: sum of squared deviations from the mean.
+// Four values per lane and iteration (16-byte loads); the tail is taken by the first threads.
 __global__ __launch_bounds__(256) void ag_reduce_partial_kernel(const float* __restrict__ v, int64_t n, int pass,
                                                                 const AgStats* __restrict__ stats,
                                                                 AgStats* __restrict__ partial) {
   __shared__ AgStats sh[4];
-  double sum = 0.0, sumsq = 0.0, vmin = 1.0e300, vmax = -1.0e300, csumsq = 0.0;
+  double sum = 0.0, sumsq = 0.0, csumsq = 0.0;
+  float vmin = 3.0e38f, vmax = -3.0e38f;
   const double mean = pass ? stats->sum / static_cast<double>(n) : 0.0;
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    const double x = v[i];
+  auto take = [&](float xf) {
+    const double x = xf;
     if (pass == 0) {
       sum += x;
       sumsq += x * x;
-      vmin = fmin(vmin, x);
-      vmax = fmax(vmax, x);
+      vmin = fminf(vmin, xf);
+      vmax = fmaxf(vmax, xf);
     } else {
       const double d = x - mean;
       csumsq += d * d;
     }
+  };
+  // elements before the first 16-byte boundary, 16-byte body, tail
+  const int64_t head = ag_align_head(v, n);
+  const int64_t n4 = (n - head) >> 2;
+  const float4* v4 = reinterpret_cast<const float4*>(v + head);
+  const int64_t tid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n4; i += nthreads) {
+    const float4 q = v4[i];
+    take(q.x);
+    take(q.y);
+    take(q.z);
+    take(q.w);
   }
+  if (tid < head) take(v[tid]);
+  if (tid < ((n - head) & 3)) take(v[head + 4 * n4 + tid]);
   sum = ag_wave_sum(sum);
   sumsq = ag_wave_sum(sumsq);
   csumsq = ag_wave_sum(csumsq);
-  vmin = ag_wave_min(vmin);
-  vmax = ag_wave_max(vmax);
+  const double dmin = ag_wave_min(static_cast<double>(vmin)), dmax = ag_wave_max(static_cast<double>(vmax));
   const int wave = threadIdx.x >> 6;
-  if (ag_lane() == 0) sh[wave] = {sum, sumsq, vmin, vmax, csumsq};
+  if (ag_lane() == 0) sh[wave] = {sum, sumsq, dmin, dmax, csumsq};
   __syncthreads();
   if (threadIdx.x == 0) {
     AgStats r = sh[0];
@@ -364,12 +385,25 @@ __global__ __launch_bounds__(256) void ag_normalise_apply_kernel(float* __restri
   } else {
     skip = true;
   }
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    float x = v[i];
+  auto apply = [&](float x) {
     if (!skip) x = (x - shift) / scale;
     if (invert) x = 1.0f - x;
-    v[i] = x;
+    return x;
+  };
+  const int64_t head = ag_align_head(v, n);
+  const int64_t n4 = (n - head) >> 2;
+  float4* v4 = reinterpret_cast<float4*>(v + head);
+  const int64_t tid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n4; i += nthreads) {
+    float4 q = v4[i];
+    q.x = apply(q.x);
+    q.y = apply(q.y);
+    q.z = apply(q.z);
+    q.w = apply(q.w);
+    v4[i] = q;
   }
+  if (tid < head) v[tid] = apply(v[tid]);
+  if (tid < ((n - head) & 3)) v[head + 4 * n4 + tid] = apply(v[head + 4 * n4 + tid]);
 }
 
 extern "C" size_t ag_normalise_workspace_bytes(int64_t n) {
@@ -388,7 +422,7 @@ extern "C" int ag_normalise(float* d_values, int64_t n, int norm, int invert, vo
   AgCarver c(d_ws);
   AgStats* stats = c.take<AgStats>(1);
   AgStats* partial = c.take<AgStats>(AG_RED_BLOCKS);
-  const int nblocks = ag_blocks(n, 256 * 8, AG_RED_BLOCKS);
+  const int nblocks = ag_blocks(n, 256 * 16, AG_RED_BLOCKS);
   if (norm != 0) {
     AG_KERNEL("ag_reduce_partial_kernel", ag_reduce_partial_kernel, dim3(nblocks), dim3(256), s, d_values, n, 0, stats, partial);
     AG_LAUNCH_CHECK();
@@ -401,7 +435,7 @@ extern "C" int ag_normalise(float* d_values, int64_t n, int norm, int invert, vo
       AG_LAUNCH_CHECK();
     }
   }
-  AG_KERNEL("ag_normalise_apply_kernel", ag_normalise_apply_kernel, dim3(ag_blocks(n, 256, 1 << 16)), dim3(256), s, d_values, n, norm, invert, stats);
+  AG_KERNEL("ag_normalise_apply_kernel", ag_normalise_apply_kernel, dim3(ag_blocks(n, 256 * 8, 1 << 14)), dim3(256), s, d_values, n, norm, invert, stats);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

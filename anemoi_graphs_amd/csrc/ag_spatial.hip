@@ -694,7 +694,7 @@ static double ag_knn_delta(int64_t ns, int k) {
 
 // list capacity of stage 1: k entries, the (k+1)-th as the boundary witness, room for an ambiguous cluster
 static int ag_knn_cap(int k, bool self_query) {
-  if (self_query) return 8;
+  if (self_query) return 8;  // self + the 6 near-equidistant neighbours of a mesh node + one witness beyond them
   const int need = k + 2;
   const int caps[] = {3, 5, 8, 12, 18, 34, AG_KNN_MAX_K + 2};
   for (int c : caps)

@@ -92,3 +92,18 @@ def test_normalise_errors_and_std_zero(device):
     assert torch.equal(ops.normalise_(v.clone(), "unit-std"), v)  # std == 0: untouched (normalise.py:49-51)
     with pytest.raises(ValueError):
         ops.normalise_(v.clone(), "l3")
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 1001, 40003])
+@pytest.mark.parametrize("norm", ["l1", "l2", "unit-max", "unit-range", "unit-std"])
+def test_normalise_any_alignment_and_length(device, offset, n, norm):
+    """The kernels read 16 bytes per lane: views that do not start on a 16-byte boundary and lengths that are
+    not multiples of 4 must give the same values (normalise.py:36-55)."""
+    rng = np.random.default_rng(n * 7 + offset)
+    full = rng.uniform(0.5, 3.0, size=n + offset).astype(np.float32)
+    t = torch.from_numpy(full).to(device)[offset:]
+    assert t.is_contiguous()
+    got = ops.normalise_(t, norm).cpu().numpy()
+    want = rp.post_process(full[offset:].reshape(-1, 1), norm)[:, 0]
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
