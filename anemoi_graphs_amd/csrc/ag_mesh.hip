@@ -41,31 +41,18 @@ static inline int ag_vertex_bits(int l) {
   return bits;
 }
 
-__global__ void ag_ico_init_kernel(double* __restrict__ xyz, int32_t* __restrict__ faces) {
-  const int i = threadIdx.x;
-  if (xyz != nullptr && i < 12) {
-    const double t = (1.0 + sqrt(5.0)) / 2.0;
-    const double n = sqrt(2.0 + t);
-    for (int c = 0; c < 3; ++c) {
-      // the table holds t as a literal; rebuild it from the same expression trimesh uses
-      const double raw = ag_ico_vertices[i][c];
-      const double v = (fabs(raw) > 1.5) ? (raw > 0 ? t : -t) : raw;
-      xyz[3 * i + c] = v / n;
-    }
-  }
-  if (i < 20)
-    for (int c = 0; c < 3; ++c) faces[3 * i + c] = ag_ico_faces[i][c];
-}
-
 __device__ __forceinline__ uint64_t ag_edge_key(int a, int b) {
   const uint32_t lo = static_cast<uint32_t>(min(a, b)), hi = static_cast<uint32_t>(max(a, b));
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
 // half-edges (a, b) with a > b: slot of b among the smaller neighbours of a
-__global__ void ag_ico_lower_kernel(const int32_t* __restrict__ faces, int64_t F, int* __restrict__ cnt,
-                                    int32_t* __restrict__ nb, int* __restrict__ error_flag) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < 3 * F; i += int64_t(gridDim.x) * blockDim.x) {
+// (the *_range functions take the first item and the stride of the calling thread, so that the same
+// code serves a grid-wide launch and the single-block kernel of the small levels; cnt / first / nb
+// may point to global memory or to LDS)
+__device__ __forceinline__ void ag_ico_lower_range(int64_t i0, int64_t step, const int32_t* faces, int64_t F, int* cnt,
+                                                   int32_t* nb, int* error_flag) {
+  for (int64_t i = i0; i < 3 * F; i += step) {
     const int64_t f = i / 3;
     const int j = static_cast<int>(i - 3 * f);
     const int a = faces[3 * f + j], b = faces[3 * f + (j == 2 ? 0 : j + 1)];
@@ -85,10 +72,10 @@ __device__ __forceinline__ void ag_cswap(int& x, int& y) {
 
 // One thread per vertex a: sort its smaller neighbours, write them back, emit the unique edges
 // (a, b_j) at first[a] + j and (optionally) their midpoints as vertices V + first[a] + j.
-__global__ void ag_ico_emit_kernel(int64_t V, int64_t Eu, const int* __restrict__ first, int32_t* __restrict__ nb,
-                                   uint64_t* __restrict__ uniq, double* __restrict__ xyz, int write_midpoints,
-                                   int* __restrict__ error_flag) {
-  for (int64_t a = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; a < V; a += int64_t(gridDim.x) * blockDim.x) {
+__device__ __forceinline__ void ag_ico_emit_range(int64_t i0, int64_t step, int64_t V, int64_t Eu, const int* first,
+                                                  int32_t* nb, uint64_t* uniq, double* xyz, int write_midpoints,
+                                                  int* error_flag) {
+  for (int64_t a = i0; a < V; a += step) {
     if (a == 0 && first[V] != Eu) *error_flag = 1;  // not a closed, consistently oriented mesh
     const int base = first[a];
     const int n = min(first[a + 1] - base, AG_MAX_DEG);
@@ -127,7 +114,7 @@ __global__ void ag_ico_emit_kernel(int64_t V, int64_t Eu, const int* __restrict_
 
 // index of the unique edge {x, y}: position of the smaller endpoint among the sorted smaller
 // neighbours of the larger one
-__device__ __forceinline__ int ag_edge_index(const int* __restrict__ first, const int32_t* __restrict__ nb, int x, int y) {
+__device__ __forceinline__ int ag_edge_index(const int* first, const int32_t* nb, int x, int y) {
   const int hi = max(x, y), lo = min(x, y);
   const int32_t* mine = nb + AG_MAX_DEG * int64_t(hi);
   const int n = first[hi + 1] - first[hi];
@@ -137,9 +124,9 @@ __device__ __forceinline__ int ag_edge_index(const int* __restrict__ first, cons
   return first[hi] + pos;
 }
 
-__global__ void ag_ico_subdivide_kernel(const int32_t* __restrict__ fin, int64_t F, const int* __restrict__ first,
-                                        const int32_t* __restrict__ nb, int V, int32_t* __restrict__ fout) {
-  for (int64_t f = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; f < F; f += int64_t(gridDim.x) * blockDim.x) {
+__device__ __forceinline__ void ag_ico_subdivide_range(int64_t i0, int64_t step, const int32_t* fin, int64_t F,
+                                                       const int* first, const int32_t* nb, int V, int32_t* fout) {
+  for (int64_t f = i0; f < F; f += step) {
     const int a = fin[3 * f], b = fin[3 * f + 1], c = fin[3 * f + 2];
     const int m0 = V + ag_edge_index(first, nb, a, b);
     const int m1 = V + ag_edge_index(first, nb, b, c);
@@ -175,11 +162,13 @@ __global__ void ag_ico_final_edges_kernel(const uint64_t* __restrict__ parent_ed
   }
 }
 
-// (also clears the slot counters for the next level: V + 1 of them)
-__global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V, int* __restrict__ cnt) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
-    cnt[i] = 0;
-    if (i == 0) cnt[V] = 0;
+// (also clears the slot counters for the next level, V + 1 of them, when cnt is given)
+__device__ __forceinline__ void ag_ico_project_range(int64_t i0, int64_t step, double* xyz, int64_t V, int* cnt) {
+  for (int64_t i = i0; i < V; i += step) {
+    if (cnt != nullptr) {
+      cnt[i] = 0;
+      if (i == 0) cnt[V] = 0;
+    }
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const double s = sqrt(x * x + y * y + z * z);
     const double off = 1.0 - s;
@@ -187,6 +176,116 @@ __global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V, int* 
     xyz[3 * i + 1] = y + (y / s) * off;
     xyz[3 * i + 2] = z + (z / s) * off;
   }
+}
+
+
+#define AG_GRID_I0 (blockIdx.x * int64_t(blockDim.x) + threadIdx.x)
+#define AG_GRID_STEP (int64_t(gridDim.x) * blockDim.x)
+
+__global__ void ag_ico_lower_kernel(const int32_t* __restrict__ faces, int64_t F, int* __restrict__ cnt,
+                                    int32_t* __restrict__ nb, int* __restrict__ error_flag) {
+  ag_ico_lower_range(AG_GRID_I0, AG_GRID_STEP, faces, F, cnt, nb, error_flag);
+}
+__global__ void ag_ico_emit_kernel(int64_t V, int64_t Eu, const int* __restrict__ first, int32_t* __restrict__ nb,
+                                   uint64_t* __restrict__ uniq, double* __restrict__ xyz, int write_midpoints,
+                                   int* __restrict__ error_flag) {
+  ag_ico_emit_range(AG_GRID_I0, AG_GRID_STEP, V, Eu, first, nb, uniq, xyz, write_midpoints, error_flag);
+}
+__global__ void ag_ico_subdivide_kernel(const int32_t* __restrict__ fin, int64_t F, const int* __restrict__ first,
+                                        const int32_t* __restrict__ nb, int V, int32_t* __restrict__ fout) {
+  ag_ico_subdivide_range(AG_GRID_I0, AG_GRID_STEP, fin, F, first, nb, V, fout);
+}
+__global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V, int* __restrict__ cnt) {
+  ag_ico_project_range(AG_GRID_I0, AG_GRID_STEP, xyz, V, cnt);
+}
+
+// The first levels are too small to fill even one CU: a launch per step costs more than the step.
+// One block of 1024 threads takes the mesh from the icosahedron through `levels` subdivisions
+// (at most AG_ICO_SMALL_LEVELS), with the slot counters, the vertex offsets and the neighbour lists
+// in LDS and workgroup barriers between the steps.  Vertices, faces and edges go to the same
+// global arrays the grid-wide kernels use, so the later levels continue from them.
+#define AG_ICO_SMALL_LEVELS 4
+#define AG_ICO_SMALL_V 642  // vertices of level AG_ICO_SMALL_LEVELS - 1, the last one subdivided here
+
+__global__ __launch_bounds__(1024) void ag_ico_small_levels_kernel(int levels, double* xyz, int32_t* faces_a,
+                                                                   int32_t* faces_b, uint64_t* level_edges,
+                                                                   uint64_t* uniq_scratch, int* g_first,
+                                                                   int* error_flag) {
+  __shared__ int s_first[AG_ICO_SMALL_V + 2];
+  __shared__ int32_t s_nb[AG_MAX_DEG * AG_ICO_SMALL_V];
+  __shared__ int s_scan[32 + 1024];
+  const int tid = threadIdx.x;
+  {  // icosahedron (trimesh.creation.icosahedron)
+    if (tid < 12) {
+      const double t = (1.0 + sqrt(5.0)) / 2.0;
+      const double n = sqrt(2.0 + t);
+      for (int c = 0; c < 3; ++c) {
+        const double raw = ag_ico_vertices[tid][c];
+        const double v = (fabs(raw) > 1.5) ? (raw > 0 ? t : -t) : raw;
+        xyz[3 * tid + c] = v / n;
+      }
+    }
+    if (tid < 20)
+      for (int c = 0; c < 3; ++c) faces_a[3 * tid + c] = ag_ico_faces[tid][c];
+  }
+  __syncthreads();
+  int32_t* cur = faces_a;
+  int32_t* nxt = faces_b;
+  for (int l = 0; l < levels; ++l) {
+    const int64_t F = 20ll << (2 * l), Eu = 30ll << (2 * l), V = (10ll << (2 * l)) + 2;
+    for (int i = tid; i <= V; i += 1024) s_first[i] = 0;
+    __syncthreads();
+    ag_ico_lower_range(tid, 1024, cur, F, s_first, s_nb, error_flag);
+    __syncthreads();
+    {  // exclusive prefix sum of s_first[0 .. V]
+      const int n = static_cast<int>(V) + 1;
+      const int per = (n + 1023) / 1024;
+      const int b = tid * per, e = min(n, b + per);
+      int local = 0;
+      for (int i = b; i < e; ++i) local += s_first[i];
+      // inclusive scan of the 1024 per-thread sums: shuffles inside each wave, then the 16 wave totals
+      int incl = local;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += v;
+      }
+      if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+      __syncthreads();
+      if (tid < 64) {
+        int w = tid < 16 ? s_scan[tid] : 0;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          const int v = __shfl_up(w, d, 64);
+          if (tid >= d) w += v;
+        }
+        if (tid < 16) s_scan[16 + tid] = w;  // inclusive totals of waves 0 .. tid
+      }
+      __syncthreads();
+      if (tid >= 64) incl += s_scan[16 + (tid >> 6) - 1];
+      s_scan[32 + tid] = incl;
+      int run = incl - local;
+      for (int i = b; i < e; ++i) {
+        const int c = s_first[i];
+        s_first[i] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    uint64_t* uniq = level_edges ? level_edges + 10 * ((int64_t(1) << (2 * l)) - 1) : uniq_scratch;
+    ag_ico_emit_range(tid, 1024, V, Eu, s_first, s_nb, uniq, xyz, 1, error_flag);
+    __syncthreads();
+    ag_ico_subdivide_range(tid, 1024, cur, F, s_first, s_nb, static_cast<int>(V), nxt);
+    __syncthreads();
+    ag_ico_project_range(tid, 1024, xyz, V + Eu, nullptr);
+    __syncthreads();
+    int32_t* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  // slot counters of the next (grid-wide) level
+  const int64_t Vn = (10ll << (2 * levels)) + 2;
+  for (int64_t i = tid; i <= Vn; i += 1024) g_first[i] = 0;
 }
 
 // descending order of a float as ascending order of an unsigned key
@@ -360,11 +459,25 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   int32_t* nxt = (R % 2 == 0) ? w.faces_a : d_faces;
   int rc = ag_zero_i32(w.error_flag, 1, s);
   if (rc) return rc;
-  rc = ag_zero_i32(w.first, ag_ico_V(0) + 1, s);
-  if (rc) return rc;
-  AG_KERNEL("ag_ico_init_kernel", ag_ico_init_kernel, dim3(1), dim3(64), s, d_xyz, cur);
+  // levels 0 .. small-1 in one block; the face ping-pong continues from where it ends
+  const int small = R < AG_ICO_SMALL_LEVELS ? R : AG_ICO_SMALL_LEVELS;
+  AG_KERNEL("ag_ico_small_levels_kernel", ag_ico_small_levels_kernel, dim3(1), dim3(1024), s, small, d_xyz, cur, nxt,
+            d_level_edges, w.uniq, w.first, w.error_flag);
   AG_LAUNCH_CHECK();
-  for (int l = 0; l < R; ++l) {
+  if (small % 2 == 1) {
+    int32_t* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  if (d_level_edges && small == R && R > 0) {
+    // the last subdivision happened inside the small kernel: its parent edges and child faces are in place
+    const int l = R - 1;
+    const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
+    AG_KERNEL("ag_ico_final_edges_kernel", ag_ico_final_edges_kernel, dim3(ag_blocks(Eu + F, 256, 8192)), dim3(256), s,
+              d_level_edges + ag_ico_edge_offset(l), Eu, V, cur, F, d_level_edges + ag_ico_edge_offset(R));
+    AG_LAUNCH_CHECK();
+  }
+  for (int l = small; l < R; ++l) {
     const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
     // the unique edges of level l go straight into the per-level edge array when the caller wants it
     uint64_t* uniq = d_level_edges ? d_level_edges + ag_ico_edge_offset(l) : w.uniq;
