@@ -27,7 +27,7 @@
 //    within one float64 ulp are not repeated.
 #include "ag_common.hpp"
 
-#define AG_ATTR_CHUNK 512  // edges per block iteration (two per thread)
+#define AG_ATTR_CHUNK 128  // edges per wave iteration (two per lane)
 
 __device__ __forceinline__ float ag_np_sin_f32(float x) {
   float s, c;
@@ -88,8 +88,6 @@ __device__ __forceinline__ double ag_atan2_pos(double y, double x) {
 struct AgAttrRuns {
   double m00[AG_ATTR_CHUNK], m01[AG_ATTR_CHUNK], m02[AG_ATTR_CHUNK], m11[AG_ATTR_CHUNK], m12[AG_ATTR_CHUNK];
   float lat[AG_ATTR_CHUNK], lon[AG_ATTR_CHUNK], cos_lat[AG_ATTR_CHUNK];
-  int tgt[AG_ATTR_CHUNK];
-  int seg[2 * 4 + 1];
 };
 
 // Target part of edges/directional.py:40-65 with generate/transforms.py:106-110,133-140: unit
@@ -176,62 +174,102 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
   }
 }
 
+// Orders the LDS traffic of one wave (its lanes run in lockstep, so no barrier is needed): global
+// loads issued before it -- the prefetch of the next chunk, the endpoint gathers of this one -- stay
+// in flight across it.
+__device__ __forceinline__ void ag_lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One wave owns a chunk of AG_ATTR_CHUNK consecutive edges (two per lane) and a private slice of LDS
+// for the runs of equal targets inside it, so waves never wait for each other.  The loop is
+// software-pipelined so that no global-memory latency is exposed inside an iteration (see below).
 __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __restrict__ src_x,
                                                             const float2* __restrict__ tgt_x,
                                                             const int32_t* __restrict__ es,
                                                             const int32_t* __restrict__ et, int64_t E, int flags,
                                                             float* __restrict__ out_len, float2* __restrict__ out_dir) {
-  __shared__ AgAttrRuns R;
+  __shared__ AgAttrRuns R_all[4];
   const bool rotated = (flags & AG_ATTR_ROTATED) != 0 && out_dir != nullptr;
   const bool want_len = out_len != nullptr, want_dir = out_dir != nullptr;
-  const int tid = threadIdx.x, lane = ag_lane(), wave = tid >> 6;
+  const int lane = ag_lane();
+  AgAttrRuns& R = R_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
   const unsigned long long below = (1ull << lane) - 1ull;
   const int64_t nchunks = (E + AG_ATTR_CHUNK - 1) / AG_ATTR_CHUNK;
-  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+  // lane l owns edges base + l and base + 64 + l.  Three chunks are in flight per wave: the ids of
+  // chunk c+2 are being fetched and the endpoints of chunk c+1 gathered while chunk c is evaluated.
+  struct Ids {
+    int t[2], s[2], p[2];
+  };
+  struct Ends {
+    float2 sp[2], tp[2];
+  };
+  auto fetch_ids = [&](int64_t chunk) {
+    Ids r;
     const int64_t base = chunk * AG_ATTR_CHUNK;
-    // thread t owns edges base + t and base + 256 + t; segment j*4 + wave holds 64 consecutive edges
-    int t_id[2], s_id[2], run[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t e = base + j * 64 + lane;
+      const bool ok = chunk < nchunks && e < E;
+      r.t[j] = ok ? et[e] : -1;
+      r.s[j] = ok ? es[e] : 0;
+      r.p[j] = (ok && e > base) ? et[e - 1] : -1;
+    }
+    return r;
+  };
+  auto gather = [&](const Ids& ids) {
+    Ends g;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = ids.t[j] >= 0;
+      g.sp[j] = ok ? src_x[ids.s[j]] : make_float2(0.f, 0.f);
+      g.tp[j] = ok ? tgt_x[ids.t[j]] : make_float2(0.f, 0.f);
+    }
+    return g;
+  };
+  Ids ids0 = fetch_ids(wave_global);
+  Ids ids1 = fetch_ids(wave_global + nwaves);
+  Ends g0 = gather(ids0);
+  for (int64_t chunk = wave_global; chunk < nchunks; chunk += nwaves) {
+    const int64_t base = chunk * AG_ATTR_CHUNK;
+    const Ends g1 = gather(ids1);
+    const Ids ids2 = fetch_ids(chunk + 2 * nwaves);
+    int run[2];
     bool valid[2], first[2];
     unsigned long long bal[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int64_t e = base + j * 256 + tid;
-      valid[j] = e < E;
-      t_id[j] = valid[j] ? et[e] : -1;
-      s_id[j] = valid[j] ? es[e] : 0;
-      const int prev = (valid[j] && e > base) ? et[e - 1] : -1;
-      first[j] = valid[j] && (e == base || prev != t_id[j]);
+      valid[j] = base + j * 64 + lane < E;
+      first[j] = valid[j] && (j * 64 + lane == 0 || ids0.p[j] != ids0.t[j]);
       bal[j] = __ballot(first[j]);
-      if (lane == 0) R.seg[j * 4 + wave] = __popcll(bal[j]);
     }
-    __syncthreads();
-    int nruns = 0;
+    const int n0 = __popcll(bal[0]);
+    const int nruns = n0 + __popcll(bal[1]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int before = 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = R.seg[q];
-        if (q < j * 4 + wave) before += c;
-        if (j == 0) nruns += c;
+      run[j] = (j ? n0 : 0) + __popcll(bal[j] & below) + (first[j] ? 1 : 0) - 1;
+      if (first[j]) {
+        R.lat[run[j]] = g0.tp[j].x;
+        R.lon[run[j]] = g0.tp[j].y;
       }
-      run[j] = before + __popcll(bal[j] & below) + (first[j] ? 1 : 0) - 1;
-      if (first[j]) R.tgt[run[j]] = t_id[j];
     }
-    __syncthreads();
-    for (int r = tid; r < nruns; r += 256) ag_attr_target(tgt_x[R.tgt[r]], rotated, R, r);
-    __syncthreads();
+    ag_lds_wave_sync();
+    for (int r = lane; r < nruns; r += 64) ag_attr_target(make_float2(R.lat[r], R.lon[r]), rotated, R, r);
+    ag_lds_wave_sync();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (!valid[j]) continue;
-      const int64_t e = base + j * 256 + tid;
+      const int64_t e = base + j * 64 + lane;
       float len;
       float2 dir;
-      ag_attr_edge(src_x[s_id[j]], R, run[j], rotated, want_len, want_dir, &len, &dir);
+      ag_attr_edge(g0.sp[j], R, run[j], rotated, want_len, want_dir, &len, &dir);
       if (want_len) out_len[e] = len;
       if (want_dir) out_dir[e] = dir;
     }
-    __syncthreads();  // the staged runs are overwritten by the next chunk
+    ag_lds_wave_sync();  // the staged runs are overwritten by the next chunk
+    ids0 = ids1;
+    ids1 = ids2;
+    g0 = g1;
   }
 }
 
@@ -241,7 +279,7 @@ extern "C" int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tg
   AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
   if (E == 0 || (d_len == nullptr && d_dir == nullptr)) return AG_OK;
   AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
-  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, AG_ATTR_CHUNK, 256 * 8)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir));
+  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, 4 * AG_ATTR_CHUNK, 256 * 8)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir));
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
