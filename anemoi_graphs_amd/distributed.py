@@ -11,9 +11,11 @@ Rank r owns band r:
   widened by the cut-off radius: the missing rows come from the two adjacent ranks (a one-hop halo
   exchange; if the radius exceeded a whole band the bands would be all-gathered instead);
 * processor (MultiScaleEdges) and TriNodes: replicated, they are a few MB;
-* raw edge attributes are computed per shard next to the edges; the edge lists and raw attributes
-  are all-gathered (variable length, rank order = target order, so the concatenation is already in
-  the single-GPU order) and the global normalisations run on the gathered arrays.
+* the edge lists are all-gathered (variable length, rank order = target order, so the
+  concatenation is already the single-GPU edge list); the all-gathers run asynchronously while the
+  next stage computes.  Edge attributes and their global normalisations are then evaluated on the
+  gathered edge lists by every rank: 8 B/edge of edge ids travel over xGMI instead of 20 B/edge, and
+  the values are bit-identical to the single-GPU build by construction.
 
 Collectives: one MAX all-reduce is avoided by replicating the reference-distance query; halo
 point-to-point send/recv with the two neighbours; all-gather of counts and of the padded edge
@@ -47,19 +49,34 @@ class Communicator:
         self.dist.all_gather(out, mine)
         return torch.stack(out).cpu()
 
-    def all_gather_rows(self, t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    def all_gather_rows(self, t: torch.Tensor, dim: int = 0, counts: list[int] | None = None) -> torch.Tensor:
         """Concatenate variable-length chunks of every rank along ``dim`` in rank order."""
+        return self.all_gather_rows_async(t, dim, counts)()
+
+    def all_gather_rows_async(self, t: torch.Tensor, dim: int = 0, counts: list[int] | None = None):
+        """Start the variable-length all-gather of ``t`` along ``dim``; the returned callable waits for
+        it and gives the concatenation in rank order.  ``counts`` (the chunk length of every rank)
+        saves the size exchange when the caller knows them."""
         device = t.device
         t = t.movedim(dim, 0).contiguous()
-        counts = self.all_gather_sizes([t.shape[0]], device)[:, 0].tolist()
+        if counts is None:
+            counts = self.all_gather_sizes([t.shape[0]], device)[:, 0].tolist()
         width = max(counts)
-        padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        padded[: t.shape[0]] = t
+        if t.shape[0] == width:
+            padded = t
+        else:
+            padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            padded[: t.shape[0]] = t
         padded = self._out(padded)
         chunks = [torch.empty_like(padded) for _ in range(self.world)]
-        self.dist.all_gather(chunks, padded)
-        out = torch.cat([c[:n] for c, n in zip(chunks, counts)], dim=0)
-        return self._back(out, device).movedim(0, dim).contiguous()
+        work = self.dist.all_gather(chunks, padded, async_op=True)
+
+        def finish() -> torch.Tensor:
+            work.wait()
+            out = torch.cat([c[:n] for c, n in zip(chunks, counts)], dim=0)
+            return self._back(out, device).movedim(0, dim).contiguous()
+
+        return finish
 
     def exchange_halo(self, to_north: torch.Tensor, to_south: torch.Tensor):
         """Send rows to the two neighbours, receive theirs: returns (from_north, from_south)."""
@@ -116,6 +133,7 @@ class ShardedGraphBuilder:
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
         self.d_lo, self.d_hi = lo, hi
         self.data_full = data_x if world_size == 1 else None
+        self.data_all = data_x  # every rank is given the complete coordinate array (53 MB for O1280)
         self.data_local = data_x[lo:hi].contiguous()
         if world_size > 1:
             lat = self.data_local[:, 0]
@@ -210,41 +228,46 @@ class ShardedGraphBuilder:
             g_lo = 0
         targets = hidden[h_lo:h_hi].contiguous()
         enc = be.radius_edges(sources, targets, radius)
-        enc_len, enc_dir = self._attrs(sources, targets, enc) if self.attributes else (None, None)
         enc = enc.clone()
         enc[0] += g_lo
         enc[1] += h_lo
+        enc_gather = comm.all_gather_rows_async(enc, dim=1)
 
         # ---- decoder: my data band as targets, replicated hidden sources
-        ids = be.knn(hidden, self.data_local, self.k)
         nt = self.data_local.shape[0]
-        dec = torch.empty((2, nt * self.k), dtype=torch.int32, device=ids.device)
-        dec[0] = ids.reshape(-1)
-        dec[1] = torch.arange(nt, dtype=torch.int32, device=ids.device).repeat_interleave(self.k)
-        dec_len, dec_dir = self._attrs(hidden, self.data_local, dec) if self.attributes else (None, None)
+        if hasattr(be, "knn_edges"):
+            dec = be.knn_edges(hidden, self.data_local, self.k)
+        else:
+            ids = be.knn(hidden, self.data_local, self.k)
+            dec = torch.empty((2, nt * self.k), dtype=torch.int32, device=ids.device)
+            dec[0] = ids.reshape(-1)
+            dec[1] = torch.arange(nt, dtype=torch.int32, device=ids.device).repeat_interleave(self.k)
         dec[1] += self.d_lo
+        band_sizes = [(self.bounds[i + 1] - self.bounds[i]) * self.k for i in range(W)]
+        dec_gather = comm.all_gather_rows_async(dec, dim=1, counts=band_sizes)
 
-        # ---- processor: replicated
+        # ---- processor: replicated, while the edge lists travel
         proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,
                                    level_edges)
-
-        # ---- gather
-        graph["data"].x = comm.all_gather_rows(self.data_local)
+        data_all = self.data_all
+        graph["data"].x = data_all
         graph["data"].node_type = "LatLonNodes"
-        for name, e, ln, dr, etype in (
-            (("data", "to", "hidden"), enc, enc_len, enc_dir, "CutOffEdges"),
-            (("hidden", "to", "data"), dec, dec_len, dec_dir, "KNNEdges"),
-        ):
-            graph[name].edge_index = comm.all_gather_rows(e, dim=1)
-            graph[name].edge_type = etype
-            if self.attributes:
-                self._finish_attrs(graph[name], comm.all_gather_rows(ln), comm.all_gather_rows(dr))
         name = ("hidden", "to", "hidden")
         graph[name].edge_index = proc
         graph[name].edge_type = "MultiScaleEdges"
         if self.attributes:
-            ln, dr = self._attrs(hidden, hidden, proc)
-            self._finish_attrs(graph[name], ln, dr)
+            self._finish_attrs(graph[name], *self._attrs(hidden, hidden, proc))
+
+        # ---- the complete edge lists; attributes on them (same kernels and inputs as a single-GPU build)
+        for name, gather, src_x, tgt_x, etype in (
+            (("data", "to", "hidden"), enc_gather, data_all, hidden, "CutOffEdges"),
+            (("hidden", "to", "data"), dec_gather, hidden, data_all, "KNNEdges"),
+        ):
+            edge_index = gather()
+            graph[name].edge_index = edge_index
+            graph[name].edge_type = etype
+            if self.attributes:
+                self._finish_attrs(graph[name], *self._attrs(src_x, tgt_x, edge_index))
         return graph
 
     def build(self) -> HeteroData:

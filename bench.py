@@ -130,12 +130,20 @@ def main() -> None:
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal knobs for a one-GPU machine: AG_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and
+    # AG_BENCH_BACKEND=gloo exchanges through host memory (RCCL refuses two ranks on one GPU)
+    if os.environ.get("AG_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("AG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
 
@@ -177,7 +185,7 @@ def main() -> None:
         profiling.enable(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -68,7 +68,7 @@ def _single(grid, resolution, factor):
     return out
 
 
-@pytest.mark.parametrize("grid,resolution,factor,world", [("o16", 2, 0.6, 2), ("reg10.0", 1, 0.6, 2), ("o16", 2, 4.0, 2)])
+@pytest.mark.parametrize("grid,resolution,factor,world", [("o16", 2, 0.6, 2), ("reg10.0", 1, 0.6, 2), ("o16", 2, 4.0, 2), ("o16", 2, 0.6, 3)])
 def test_sharded_build_equals_single(tmp_path, grid, resolution, factor, world):
     """Third case: a radius wider than a band forces the all-gather fallback instead of the halo."""
     port = _free_port()

@@ -1,0 +1,70 @@
+"""GPU, two processes sharing the one GPU over gloo (tensors staged through host memory): the
+latitude-band sharded build with the HIP kernels yields exactly the single-process graph."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from anemoi_graphs_amd import grids
+
+pytestmark = pytest.mark.gpu
+
+NAMES = (("data", "to", "hidden"), ("hidden", "to", "data"), ("hidden", "to", "hidden"))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dump(g, path):
+    out = {}
+    for name in NAMES:
+        key = "_".join(name)
+        out[key] = g[name].edge_index.cpu().numpy()
+        out[key + "_len"] = g[name]["edge_length"].cpu().numpy()
+        out[key + "_dir"] = g[name]["edge_dirs"].cpu().numpy()
+    np.savez(path, **out)
+
+
+def _worker(rank, world, port, grid, resolution, factor, out_dir):
+    from anemoi_graphs_amd import settings
+    from anemoi_graphs_amd.distributed import ShardedGraphBuilder
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        data = torch.from_numpy(grids.named(grid)).to("cuda:0")
+        b = ShardedGraphBuilder(data, resolution, cutoff_factor=factor, num_nearest_neighbours=3, x_hops=1, rank=rank,
+                                world_size=world, dist=dist, edge_length_norm="unit-max", edge_direction_norm="unit-std")
+        with settings.resident(True):
+            g = b.build()
+        _dump(g, os.path.join(out_dir, f"rank{rank}.npz"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,resolution,factor,world", [("o96", 4, 0.6, 2), ("o320", 5, 0.6, 3), ("o96", 3, 3.0, 2)])
+def test_sharded_hip_build_equals_single(device, tmp_path, grid, resolution, factor, world):
+    from anemoi_graphs_amd import settings
+    from anemoi_graphs_amd.distributed import ShardedGraphBuilder
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path)), nprocs=world, join=True)
+    data = torch.from_numpy(grids.named(grid)).to(device)
+    single = ShardedGraphBuilder(data, resolution, cutoff_factor=factor, num_nearest_neighbours=3, x_hops=1,
+                                 edge_length_norm="unit-max", edge_direction_norm="unit-std")
+    with settings.resident(True):
+        g = single.build()
+    _dump(g, tmp_path / "single.npz")
+    want = np.load(tmp_path / "single.npz")
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for key in want.files:
+            assert np.array_equal(got[key], want[key]), f"rank {r} {key}"
