@@ -868,7 +868,7 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
 // ---------------------------------------------------------------------------------------------
 #define AG_ROW_LDS 1024  // row entries a wave can sort in LDS
 #define AG_STASH_MAX 256  // longest row the count pass keeps for the fill pass
-#define AG_STASH_BUDGET (int64_t(1) << 26)  // entries of the stash over all targets
+#define AG_STASH_BUDGET (int64_t(1) << 28)  // entries of the stash over all targets (1 GiB)
 #define AG_RADIUS_RUNS 8  // runs of binned sources in a target's window (3 bands x 2 + spare)
 
 // What the search needs to know about a target, computed once per target by one thread

@@ -36,6 +36,7 @@ WORKLOADS = {
     "o1280_r7": ("o1280", 7),
     "era5_r6": ("era5", 6),
     "o96_r4": ("o96", 4),
+    "o3600_r9": ("o3600", 9),  # 52 M data nodes, 2.6 M hidden nodes: a size check, not a headline
 }
 CUTOFF_FACTOR = 0.6
 KNN_K = 3
