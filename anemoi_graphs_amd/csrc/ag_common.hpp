@@ -366,6 +366,10 @@ int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t*
 size_t ag_sort_pairs_u64_i32_temp_bytes(int64_t n);
 int ag_sort_pairs_u64_i32(void* d_temp, size_t temp_bytes, const uint64_t* d_keys_in, uint64_t* d_keys_out,
                           const int32_t* d_vals_in, int32_t* d_vals_out, int64_t n, hipStream_t stream);
+size_t ag_segmented_sort_i32_temp_bytes(int64_t segments);
+int ag_segmented_sort_i32(void* d_temp, size_t temp_bytes, int32_t* d_a, int32_t* d_b, int64_t size, int64_t segments,
+                          const uint32_t* d_begin, const uint32_t* d_end, int end_bit, bool* sorted_in_b,
+                          hipStream_t stream);
 size_t ag_scan_i32_temp_bytes(int64_t n);
 // exclusive prefix sum of n int32 values, in place allowed
 int ag_exclusive_scan_i32(void* d_temp, size_t temp_bytes, const int* d_in, int* d_out, int64_t n, hipStream_t stream);

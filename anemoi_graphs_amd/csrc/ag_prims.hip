@@ -159,6 +159,32 @@ int ag_sort_pairs_u64_i32(void* d_temp, size_t temp_bytes, const uint64_t* d_key
   return AG_OK;
 }
 
+// Sorts every segment [begin[i], end[i]) of int32 keys ascending on bits [0, end_bit); the keys live
+// in one of two buffers of `size` elements and *sorted_in_b tells where the result is.
+size_t ag_segmented_sort_i32_temp_bytes(int64_t segments) {
+  size_t bytes = 0;
+  int32_t* p = nullptr;
+  rocprim::double_buffer<int32_t> keys(p, p);
+  const uint32_t* o = nullptr;
+  (void)rocprim::segmented_radix_sort_keys(nullptr, bytes, keys, 1u << 30, static_cast<unsigned>(segments > 0 ? segments : 1),
+                                           o, o, 0u, 32u, hipStream_t(0));
+  return bytes + 256;
+}
+
+int ag_segmented_sort_i32(void* d_temp, size_t temp_bytes, int32_t* d_a, int32_t* d_b, int64_t size, int64_t segments,
+                          const uint32_t* d_begin, const uint32_t* d_end, int end_bit, bool* sorted_in_b,
+                          hipStream_t stream) {
+  if (size >= (int64_t(1) << 32) || segments >= (int64_t(1) << 32))
+    return ag_fail(AG_ERR_INVALID, "segmented sort: more than 2^32 items");
+  rocprim::double_buffer<int32_t> keys(d_a, d_b);
+  AgProfScope prof("rocprim_segmented_radix_sort", stream);
+  AG_HIP(rocprim::segmented_radix_sort_keys(d_temp, temp_bytes, keys, static_cast<unsigned>(size),
+                                            static_cast<unsigned>(segments), d_begin, d_end, 0u,
+                                            static_cast<unsigned>(end_bit), stream));
+  *sorted_in_b = keys.current() == d_b;
+  return AG_OK;
+}
+
 size_t ag_scan_i32_temp_bytes(int64_t n) {
   size_t bytes = 0;
   int* p = nullptr;

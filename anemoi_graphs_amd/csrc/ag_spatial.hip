@@ -1083,42 +1083,64 @@ __global__ __launch_bounds__(256) void ag_radius_copy_kernel(AgRadiusArgs a) {
   }
 }
 
-// Fill pass, rows longer than the stash: searched again, sorted in LDS (up to AG_ROW_LDS entries)
-// or in place in global memory.
-__global__ __launch_bounds__(256) void ag_radius_long_kernel(AgRadiusArgs a) {
-  __shared__ __attribute__((aligned(16))) int row_all[4][AG_ROW_LDS + 4];
+// Fill pass, rows longer than the stash: searched again, the unsorted ids go to the row's piece of
+// the TARGET column (scratch until the row is finished); every row also gets its segment
+// [begin, end) for the segmented sort -- empty for the rows the copy kernel already wrote.
+__global__ __launch_bounds__(256) void ag_radius_long_kernel(AgRadiusArgs a, uint32_t* __restrict__ seg_begin,
+                                                             uint32_t* __restrict__ seg_end) {
   const int lane = ag_lane();
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int* row = row_all[wave];
+  const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t t = wave_global; t < a.nt; t += nwaves) {
+    const int64_t base_out = a.offsets[t];
+    const int64_t n_row = a.offsets[t + 1] - base_out;
+    const bool is_long = n_row > a.stash_cap;
+    if (lane == 0) {
+      seg_begin[t] = is_long ? static_cast<uint32_t>(base_out) : 0u;
+      seg_end[t] = is_long ? static_cast<uint32_t>(base_out + n_row) : 0u;
+    }
+    if (is_long) (void)ag_radius_scan(a, t, nullptr, 0, a.out_tgt + base_out);
+  }
+}
+
+// after the segmented sort: long rows get their sorted sources (when the sort left them in the
+// target column) and their target ids
+__global__ __launch_bounds__(256) void ag_radius_long_finish_kernel(AgRadiusArgs a, int sorted_in_tgt) {
+  const int lane = ag_lane();
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
   for (int64_t t = wave_global; t < a.nt; t += nwaves) {
     const int64_t base_out = a.offsets[t];
     const int64_t n_row = a.offsets[t + 1] - base_out;
     if (n_row <= a.stash_cap) continue;
-    if (n_row <= AG_ROW_LDS) {
-      (void)ag_radius_scan(a, t, row, AG_ROW_LDS, nullptr);
-      ag_wave_sync_lds();
-      ag_row_rank_sort(row, static_cast<int>(n_row), a.out_src + base_out);
-      for (int e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
-      ag_wave_sync_lds();
-    } else {
-      // the target column doubles as scratch for long rows; source ids are distinct inside a
-      // row, so rank = number of smaller ids
-      (void)ag_radius_scan(a, t, nullptr, 0, a.out_tgt + base_out);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int64_t e = lane; e < n_row; e += 64) {
-        const int mine = a.out_tgt[base_out + e];
-        int64_t rank = 0;
-        for (int64_t j = 0; j < n_row; ++j) rank += (a.out_tgt[base_out + j] < mine) ? 1 : 0;
-        a.out_src[base_out + rank] = mine;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int64_t e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
+    for (int64_t e = lane; e < n_row; e += 64) {
+      if (sorted_in_tgt) a.out_src[base_out + e] = a.out_tgt[base_out + e];
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t e = lane; e < n_row; e += 64) a.out_tgt[base_out + e] = static_cast<int32_t>(t);
   }
+}
+
+// largest row of the count pass (before the counts are turned into offsets)
+__global__ __launch_bounds__(256) void ag_radius_max_row_kernel(const int64_t* __restrict__ counts, int64_t nt,
+                                                                unsigned long long* __restrict__ out) {
+  __shared__ long long sh[4];
+  long long m = 0;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < nt; i += int64_t(gridDim.x) * blockDim.x)
+    m = max(m, static_cast<long long>(counts[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if (ag_lane() == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+    atomicMax(out, static_cast<unsigned long long>(m));
+  }
+}
+
+__global__ void ag_radius_store_max_kernel(const unsigned long long* __restrict__ m, int64_t* __restrict__ out) {
+  *out = static_cast<int64_t>(*m);
 }
 
 struct AgRadiusWs {
@@ -1128,6 +1150,10 @@ struct AgRadiusWs {
   int32_t* stash;
   int stash_cap;
   AgRadiusDesc* desc;
+  uint32_t *seg_begin, *seg_end;  // [nt] segments of the rows longer than the stash
+  void* seg_temp;
+  size_t seg_temp_bytes;
+  unsigned long long* max_row;
 };
 
 // cell size for a radius query: the query radius itself, but never so small that the grid has
@@ -1162,7 +1188,17 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
   const int cap = ag_radius_stash_cap(nt);
   int32_t* stash = c.take<int32_t>(nt * cap + 4);
   AgRadiusDesc* desc = c.take<AgRadiusDesc>(nt);
+  uint32_t* seg_begin = c.take<uint32_t>(nt);
+  uint32_t* seg_end = c.take<uint32_t>(nt);
+  const size_t seg_temp_bytes = ag_segmented_sort_i32_temp_bytes(nt);
+  void* seg_temp = c.take<char>(seg_temp_bytes);
+  unsigned long long* max_row = c.take<unsigned long long>(2);
   if (w) {
+    w->seg_begin = seg_begin;
+    w->seg_end = seg_end;
+    w->seg_temp = seg_temp;
+    w->seg_temp_bytes = seg_temp_bytes;
+    w->max_row = max_row;
     w->desc = desc;
     w->scan_temp = st;
     w->scan_temp_bytes = stb;
@@ -1229,14 +1265,26 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
     AG_KERNEL("ag_radius_count_kernel", ag_radius_count_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
-  return ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
+  // offsets[nt + 1] = the longest row (taken from the counts, before they become offsets)
+  int rcz = ag_zero_i32(reinterpret_cast<int*>(w.max_row), 2, s);
+  if (rcz) return rcz;
+  if (nt > 0) {
+    AG_KERNEL("ag_radius_max_row_kernel", ag_radius_max_row_kernel, dim3(ag_blocks(nt, 256 * 8, 256)), dim3(256), s,
+              d_offsets, nt, w.max_row);
+    AG_LAUNCH_CHECK();
+  }
+  int rc2 = ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
+  if (rc2) return rc2;
+  AG_KERNEL("ag_radius_store_max_kernel", ag_radius_store_max_kernel, dim3(1), dim3(1), s, w.max_row, d_offsets + nt + 1);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
 }
 
 extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
-                              const int64_t* d_offsets, int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws,
-                              size_t ws_bytes, void* stream) {
-  AG_REQUIRE(ns >= 1 && nt >= 0, "ag_radius_fill: bad sizes");
-  if (nt == 0) return AG_OK;
+                              const int64_t* d_offsets, int64_t num_edges, int64_t max_row, int32_t* d_out_src,
+                              int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream) {
+  AG_REQUIRE(ns >= 1 && nt >= 0 && num_edges >= 0 && max_row >= 0, "ag_radius_fill: bad sizes");
+  if (nt == 0 || num_edges == 0) return AG_OK;
   AG_REQUIRE(d_src && d_tgt && d_offsets && d_out_src && d_out_tgt && d_ws, "ag_radius_fill: null pointer");
   if (ws_bytes < ag_radius_workspace_bytes(ns, nt)) return ag_fail(AG_ERR_WORKSPACE, "ag_radius_fill: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1253,7 +1301,22 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
     AG_KERNEL("ag_radius_copy_kernel", ag_radius_copy_kernel, dim3(ag_blocks(nt, AG_COPY_GROUP, 16384)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
-  AG_KERNEL("ag_radius_long_kernel", ag_radius_long_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
+  if (max_row <= a.stash_cap) return AG_OK;
+  // rows longer than the stash: search again into the target column, sort every such row by source
+  // id with one segmented radix sort, then write the target ids
+  AG_REQUIRE(num_edges < (int64_t(1) << 32), "ag_radius_fill: rows longer than %d entries need fewer than 2^32 edges",
+             a.stash_cap);
+  AG_KERNEL("ag_radius_long_kernel", ag_radius_long_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a, w.seg_begin,
+            w.seg_end);
+  AG_LAUNCH_CHECK();
+  int id_bits = 1;
+  while ((int64_t(1) << id_bits) < ns) ++id_bits;
+  bool sorted_in_src = false;
+  rc = ag_segmented_sort_i32(w.seg_temp, w.seg_temp_bytes, d_out_tgt, d_out_src, num_edges, nt, w.seg_begin, w.seg_end,
+                             id_bits, &sorted_in_src, s);
+  if (rc) return rc;
+  AG_KERNEL("ag_radius_long_finish_kernel", ag_radius_long_finish_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a,
+            sorted_in_src ? 0 : 1);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -117,18 +117,18 @@ def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float) -> torch.T
     ns, nt = src.shape[0], tgt.shape[0]
     radius = float(radius)
     with torch.cuda.device(dev):
-        offsets = torch.empty(nt + 1, dtype=torch.int64, device=dev)
+        offsets = torch.empty(nt + 2, dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
         _lib.check(
             lib.ag_radius_count(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), _ptr(ws), ws.numel(), _stream(dev)),
             "ag_radius_count",
         )
-        num_edges = int(offsets[nt].item())  # the one host synchronisation: the output size
+        num_edges, max_row = offsets[nt:].tolist()  # the one host synchronisation: output size, longest row
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
         if num_edges:
             _lib.check(
-                lib.ag_radius_fill(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), _ptr(edge_index[0]),
-                                   _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
+                lib.ag_radius_fill(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), num_edges, max_row,
+                                   _ptr(edge_index[0]), _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_radius_fill",
             )
     return edge_index

@@ -76,17 +76,20 @@ int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, 
  * (edges/builder.py:364-366): all (source, target) pairs with rdist <= sin^2(radius/2).
  * Two calls sharing one workspace: ag_radius_count bins the sources and writes the
  * exclusive prefix sum of the per-target match counts to d_offsets[0..nt] (d_offsets[nt] =
- * number of edges E); the caller reads E, allocates, and calls ag_radius_fill with the SAME
- * arguments and the SAME untouched workspace.  Rows are target-major; inside a row source
- * ids ascend (the rows are sorted in LDS before they are written).  d_out_tgt [E] is required:
- * it receives the target id of every edge and serves as scratch for rows longer than 1024.
+ * number of edges E) and the longest row to d_offsets[nt + 1] -- d_offsets holds nt + 2
+ * entries; the caller reads both, allocates, and calls ag_radius_fill with the SAME arguments,
+ * the two values and the SAME untouched workspace.  Rows are target-major; inside a row source
+ * ids ascend.  Rows of up to 256 entries are sorted in LDS by the count pass and only copied by
+ * the fill pass; longer rows are searched again and ordered by one segmented radix sort (that
+ * path needs E < 2^32).  d_out_tgt [E] is required: it receives the target id of every edge
+ * and serves as scratch for the long rows.
  */
 size_t ag_radius_workspace_bytes(int64_t ns, int64_t nt);
 int ag_radius_count(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
                     int64_t* d_offsets, void* d_ws, size_t ws_bytes, void* stream);
 int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
-                   const int64_t* d_offsets, int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws,
-                   size_t ws_bytes, void* stream);
+                   const int64_t* d_offsets, int64_t num_edges, int64_t max_row, int32_t* d_out_src,
+                   int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Icosphere nodes.

@@ -146,3 +146,27 @@ def test_radius_golden(device, golden):
     src, tgt, radius = g["data"], g["hidden"], float(g["enc_cutoff06_radius"])
     e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius).cpu().numpy()
     assert np.array_equal(e, h.canonical(g["enc_cutoff06_edge_index"]))
+
+
+@pytest.mark.parametrize("ns,nt,radius", [(200000, 400, 0.08), (200000, 300, 0.5), (60000, 50, 2.5)])
+def test_radius_long_rows(device, ns, nt, radius):
+    """Rows of hundreds to tens of thousands of sources: beyond what the count pass keeps, ordered by
+    the segmented sort (mixed with short and empty rows: half the targets sit in a source-free cap)."""
+    src = grids.random_sphere(ns, seed=31)
+    src = src[src[:, 0] < 0.9]  # no sources near the north pole
+    tgt = grids.random_sphere(nt, seed=32)
+    tgt[: nt // 2, 0] = 1.5  # targets near the pole: short or empty rows for small radii
+    res = _radius_case(src, tgt, radius, device)
+    e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius)
+    rows = np.bincount(e[1].cpu().numpy(), minlength=nt)
+    assert rows.max() > 256
+    print("long rows", radius, res, "max row", rows.max(), "empty rows", int((rows == 0).sum()))
+
+
+def test_radius_o1280_to_r4(device):
+    """A coarse hidden mesh under a dense data grid: every row has thousands of entries."""
+    data = grids.octahedral(320)
+    hidden, _ = rp.tri_nodes(3)
+    radius = rp.cutoff_radius(hidden, 0.6)
+    res = _radius_case(data, hidden, radius, device)
+    print(res)
