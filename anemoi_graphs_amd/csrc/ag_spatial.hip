@@ -224,8 +224,9 @@ struct AgKnnArgs {
   float rg_chord2;           // conservative float32 chord^2 of rg
   int32_t* out_src;          // [nt*k]
   double* out_dist;          // [nt*k] or null
-  int* cand_n;               // [nt] per binned target: number of candidates to re-rank in float64 (0 = none)
-  int* cand_ids;             // [CAP][nt] candidate ids, coalesced per rank
+  int* cand_n;               // [nt] per re-rank queue slot: number of candidates to re-rank in float64
+  int* cand_t;               // [nt] per re-rank queue slot: the binned target
+  int* cand_ids;             // [CAP][nt] candidate ids by queue slot, coalesced per rank
   int* queue;                // [nt] targets left to stage 2
   int* queue_count;
   const struct AgWindow* windows;  // [target cells] precomputed source runs
@@ -497,12 +498,33 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       for (int j = 0; j < CAP; ++j)
         if (j < k) o[j] = bi[j];
     }
-    if (RESOLVE && active) {
-      const bool rec = done && exact;
-      a.cand_n[ti] = rec ? c1 + 1 : 0;
-      if (rec) {
+    if (RESOLVE) {
+      // targets whose list has to be re-ranked in float64 are appended to a queue (one atomic per
+      // wave); the candidate lists are stored by queue slot, coalesced per rank
+      const bool rec = active && done && exact;
+      const unsigned long long m = __ballot(rec);
+      if (a.self_query) {
+        // every target is re-ranked (the value of its 2nd smallest rdist is needed): slot = target
+        if (active) {
+          a.cand_n[ti] = rec ? c1 + 1 : 0;
+          a.cand_t[ti] = ti;
+          if (rec) {
 #pragma unroll
-        for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.nt + ti] = bi[j];
+            for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.nt + ti] = bi[j];
+          }
+        }
+      } else if (m) {
+        int base = 0;
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        if (lane == leader) base = atomicAdd(a.queue_count + 1, __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (rec) {
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          a.cand_n[slot] = c1 + 1;
+          a.cand_t[slot] = ti;
+#pragma unroll
+          for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.nt + slot] = bi[j];
+        }
       }
     }
     if (queued) {
@@ -521,9 +543,11 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
   __shared__ double sh[4];
   double my_max = 0.0;
   const int k = a.k;
-  for (int64_t ti = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; ti < a.nt; ti += int64_t(gridDim.x) * blockDim.x) {
-    const int n = a.cand_n[ti];
+  const int64_t nslots = a.self_query ? a.nt : a.queue_count[1];
+  for (int64_t slot = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; slot < nslots; slot += int64_t(gridDim.x) * blockDim.x) {
+    const int n = a.cand_n[slot];
     if (n == 0) continue;
+    const int ti = a.cand_t[slot];
     const int tid = a.tids[ti];
     const float2 tp = a.tgt[tid];
     double rr[CAP];
@@ -533,7 +557,7 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
       rr[j] = 1.0e300;
       bi[j] = 0x7fffffff;
       if (j < n) {
-        bi[j] = a.cand_ids[static_cast<int64_t>(j) * a.nt + ti];
+        bi[j] = a.cand_ids[static_cast<int64_t>(j) * a.nt + slot];
         const float2 p = a.src[bi[j]];
         rr[j] = ag_rdist(tp.x, tp.y, p.x, p.y);
       }
@@ -670,7 +694,8 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
 
 __global__ void ag_knn_init_kernel(int* queue_count, unsigned long long* max_bits, long long* stats) {
   if (threadIdx.x == 0) {
-    *queue_count = 0;
+    queue_count[0] = 0;  // stage-2 queue
+    queue_count[1] = 0;  // float64 re-rank queue
     if (max_bits) *max_bits = 0ull;
     if (stats) {
       stats[0] = stats[1] = stats[2] = stats[3] = 0;
@@ -719,6 +744,7 @@ struct AgKnnWs {
   int* queue_count;
   unsigned long long* max_bits;
   int* cand_n;
+  int* cand_t;
   int* cand_ids;
   struct AgWindow* windows;
 };
@@ -736,6 +762,7 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* queue_count = c.take<int>(4);
   unsigned long long* max_bits = c.take<unsigned long long>(2);
   int* cand_n = cap <= 12 ? c.take<int>(nt) : nullptr;
+  int* cand_t = cap <= 12 ? c.take<int>(nt) : nullptr;
   int* cand_ids = cap <= 12 ? c.take<int>(nt * cap) : nullptr;
   AgWindow* windows = c.take<AgWindow>(ag_grid_cells_ub(nb, tmult) + 1);
   if (w) {
@@ -745,6 +772,7 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
     w->queue_count = queue_count;
     w->max_bits = max_bits;
     w->cand_n = cand_n;
+    w->cand_t = cand_t;
     w->cand_ids = cand_ids;
   }
   return AG_OK;
@@ -794,6 +822,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.out_src = d_out_src;
   a.out_dist = d_out_dist;
   a.cand_n = w.cand_n;
+  a.cand_t = w.cand_t;
   a.cand_ids = w.cand_ids;
   a.queue = w.queue;
   a.queue_count = w.queue_count;
