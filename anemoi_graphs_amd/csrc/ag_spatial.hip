@@ -39,7 +39,8 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
     const double lat_hi = AG_HALF_PI - b * dlat, lat_lo = lat_hi - dlat;
     const double mid = AG_HALF_PI - (b + 0.5) * dlat;
     int nc = static_cast<int>(floor(AG_TWO_PI * ag_cos_f64(mid) / dlat));
-    nc = max(nc, 1) * mult;
+    nc = max(nc, 1);
+    nc = mult >= 0 ? nc * mult : max(1, nc / (-mult));  // negative: merge -mult cells into one
     ncols[b] = nc;
     sum += nc;
     // longitude half-width of a cap of radius rg centred anywhere in the band (see ag_for_each_range)
@@ -131,7 +132,7 @@ int ag_grid_bands(double delta) {
 
 static int64_t ag_grid_cells_ub(int nb, int mult = 1) {
   const double dlat = AG_PI / nb;
-  return (static_cast<int64_t>(4.0 * AG_PI / (dlat * dlat) * 1.02) + nb + 64) * mult;
+  return (static_cast<int64_t>(4.0 * AG_PI / (dlat * dlat) * 1.02) + nb + 64) * (mult > 1 ? mult : 1);
 }
 
 struct AgBinCarve {
@@ -727,10 +728,18 @@ static int ag_knn_cap(int k, bool self_query) {
   return AG_KNN_MAX_K + 2;
 }
 
-// longitude-cell multiplier of the target grid: about 48 targets per target cell
+// Longitude cells of the target grid relative to the source grid, aiming at about 48 targets per
+// target cell (one wave pass holds 64): m > 0 cuts every source cell into m target cells (dense
+// targets), m < 0 merges -m source cells into one target cell (sparse targets: the window grows by
+// the merged cells, but the lanes of a wave fill up).
 static int ag_knn_tmult(int64_t nt, int nb) {
   const double dlat = AG_PI / nb;
   const double per_cell = static_cast<double>(nt) / (4.0 * AG_PI / (dlat * dlat));
+  if (per_cell < 24.0) {
+    int g = static_cast<int>(floor(48.0 / (per_cell > 1.0e-9 ? per_cell : 1.0e-9)));
+    if (g > 16) g = 16;
+    return g >= 2 ? -g : 1;
+  }
   int m = static_cast<int>(ceil(per_cell / 48.0));
   if (m < 1) m = 1;
   if (m > 64) m = 64;
