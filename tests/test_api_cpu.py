@@ -133,3 +133,35 @@ def test_no_silent_fallback_without_a_gpu():
         ops.knn(torch.zeros((4, 2)), torch.zeros((4, 2)), 1)
     with pytest.raises(RuntimeError):
         TriNodes(1, "h").update_graph(HeteroData(), {})
+
+
+# ---- /root/reference/tests/generate/test_masks.py:17-39 -------------------------------------------------
+
+
+def test_area_mask_builder_init():
+    from anemoi_graphs_amd.generate import KNNAreaMaskBuilder
+
+    for kwargs in ({}, {"margin_radius_km": 120}, {"mask_attr_name": "mask"},
+                   {"margin_radius_km": 120, "mask_attr_name": "mask"}):
+        assert isinstance(KNNAreaMaskBuilder("nodes", **kwargs), KNNAreaMaskBuilder)
+
+
+@pytest.mark.parametrize("margin", [-1, "120", None])
+def test_area_mask_builder_fail_init_wrong_margin(margin):
+    from anemoi_graphs_amd.generate import KNNAreaMaskBuilder
+
+    with pytest.raises(AssertionError):
+        KNNAreaMaskBuilder("nodes", margin_radius_km=margin)
+
+
+def test_limited_area_and_stretched_builders_construct_like_the_reference():
+    """from_refined_icosahedron.py:81-92,159-172: constructor arguments, resolutions, mask builder."""
+    from anemoi_graphs_amd.nodes import LimitedAreaTriNodes, StretchedTriNodes
+
+    lam = LimitedAreaTriNodes(3, "ref", "hidden", margin_radius_km=50.0)
+    assert lam.resolutions == [0, 1, 2, 3] and lam.area_mask_builder.margin_radius_km == 50.0
+    assert lam.area_mask_builder.reference_node_name == "ref"
+    st = StretchedTriNodes(2, 5, "hidden", "ref", "cutout")
+    assert st.global_resolution == 2 and st.resolutions == list(range(6))
+    assert st.area_mask_builder.mask_attr_name == "cutout"
+    assert {"resolutions", "nx_graph", "node_ordering", "area_mask_builder"} <= set(st.hidden_attributes)
