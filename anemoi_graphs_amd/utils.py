@@ -20,7 +20,12 @@ def get_grid_reference_distance(coords_rad: torch.Tensor, mask: torch.Tensor | N
     assert mask is None or mask.shape == (coords_rad.shape[0], 1), (
         "Mask must have the same shape as the number of nodes."
     )
-    return float(ops.nn_maxdist(coords_rad).item())
+    value = float(ops.nn_maxdist(coords_rad).item())
+    if value == 0.0:
+        # every node coincides with another one: the reference takes dists[dists > 0].max() of an empty
+        # selection, which numpy refuses with exactly this error (utils.py:61-63)
+        raise ValueError("zero-size array to reduction operation maximum which has no identity")
+    return value
 
 
 def concat_edges(edge_indices1: torch.Tensor, edge_indices2: torch.Tensor) -> torch.Tensor:
