@@ -128,7 +128,7 @@ def case_regular(ref):
 
 
 def case_o96_tri4(ref):
-    """configs[0] of BASELINE.json: O96 (40,320) -> TriNodes r=4, KNNEdges k=3 (decoder direction)
+    """The small plumbing configuration: O96 (40,320) -> TriNodes r=4, KNNEdges k=3 (decoder direction)
     plus the CutOff encoder, through the reference's own classes."""
     data = grids.octahedral(96)
     g = _graph(ref, data=data)
