@@ -347,7 +347,6 @@ struct AgBinned {
   const float4* pts = nullptr;  // [n]  (x, y, z, bits of original id) in binned order (optional)
   const int* ids = nullptr;     // [n]  original id of every binned position
   const int* cell_start = nullptr; // [ncells_ub + 1]
-  const int* cell_band = nullptr;  // [ncells_ub] band of every cell (grids binned without unit vectors)
 };
 
 // Number of latitude bands for cells of about `delta` radians.

@@ -26,8 +26,13 @@
 // ---------------------------------------------------------------------------------------------
 // grid construction
 // ---------------------------------------------------------------------------------------------
+// Block 0 computes the band tables; every block clears its share of the cell counters.
 __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat, int mult, int* __restrict__ ncols,
-                                                             int* __restrict__ off, double* __restrict__ win) {
+                                                             int* __restrict__ off, double* __restrict__ win,
+                                                             int* __restrict__ cell_count, int64_t ncount) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < ncount; i += int64_t(gridDim.x) * blockDim.x)
+    cell_count[i] = 0;
+  if (blockIdx.x != 0) return;
   __shared__ int partial[1024];
   const int tid = threadIdx.x;
   const int per = (nb + 1023) / 1024;
@@ -68,17 +73,14 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
   if (tid == 1023) off[nb] = partial[1023];
 }
 
-// band of every cell (one thread per cell, binary search in the band offsets)
-__global__ void ag_cell_band_kernel(AgGrid g, int* __restrict__ cell_band) {
-  const int ncells = g.off[g.nb];
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncells; c += gridDim.x * blockDim.x) {
-    int lo = 0, hi = g.nb - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (g.off[mid] <= c) lo = mid; else hi = mid - 1;
-    }
-    cell_band[c] = lo;
+// band of a cell: binary search in the band offsets
+__device__ __forceinline__ int ag_band_of_cell(const AgGrid& g, int c) {
+  int lo = 0, hi = g.nb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (g.off[mid] <= c) lo = mid; else hi = mid - 1;
   }
+  return lo;
 }
 
 __global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n, int* __restrict__ cell_of,
@@ -136,7 +138,7 @@ static int64_t ag_grid_cells_ub(int nb, int mult = 1) {
 }
 
 struct AgBinCarve {
-  int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids, *cell_band;
+  int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids;
   double* win;
   float4* pts;
   void* scan_temp;
@@ -155,7 +157,6 @@ static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool
   c->scan_temp_bytes = ag_scan_i32_temp_bytes(cells);
   c->scan_temp = ws.take<char>(c->scan_temp_bytes);
   c->pts = want_pts ? ws.take<float4>(n) : nullptr;
-  c->cell_band = want_pts ? nullptr : ws.take<int>(cells);  // target grids carry the cell -> band table
 }
 
 static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, int mult, AgBinned* out) {
@@ -167,7 +168,6 @@ static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, int mult, Ag
   out->grid.win = c.win;
   out->n = n;
   out->ncells_ub = ag_grid_cells_ub(nb, mult);
-  out->cell_band = c.cell_band;
   out->pts = c.pts;
   out->ids = c.ids;
   out->cell_start = c.cell_start;
@@ -181,16 +181,10 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   if (out == nullptr) return AG_OK;  // sizing pass
   ag_bin_describe(c, n, nb, mult, out);
   const int64_t ncells_ub = out->ncells_ub;
-  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(1), dim3(1024), stream, nb, out->grid.dlat, mult,
-            c.ncols, c.off, c.win);
+  AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(ncells_ub + 1, 4096, 256)), dim3(1024), stream,
+            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1);
   AG_LAUNCH_CHECK();
-  if (c.cell_band != nullptr) {
-    AG_KERNEL("ag_cell_band_kernel", ag_cell_band_kernel, dim3(ag_blocks(ncells_ub, 256, 4096)), dim3(256), stream,
-              out->grid, c.cell_band);
-    AG_LAUNCH_CHECK();
-  }
-  int rc = ag_zero_i32(c.cell_start, ncells_ub + 1, stream);
-  if (rc) return rc;
+  int rc = AG_OK;
   const int blocks = ag_blocks(n, 256, 16384);
   AG_KERNEL("ag_bin_count_kernel", ag_bin_count_kernel, dim3(blocks), dim3(256), stream, out->grid,
             reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start);
@@ -216,7 +210,6 @@ struct AgKnnArgs {
   const int* sstart;         // source cell starts
   const int* tids;           // binned target ids
   const int* tstart;         // target cell starts
-  const int* tband;          // band of every target cell
   const float2* tgt;         // target coordinates, original order
   const float2* src;         // source coordinates, original order
   int64_t ns, nt;
@@ -312,7 +305,7 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   const int ncells = a.tgrid.off[a.tgrid.nb];
   for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += gridDim.x * blockDim.x) {
     if (a.tstart[cell] >= a.tstart[cell + 1]) continue;
-    const int band = a.tband[cell];
+    const int band = ag_band_of_cell(a.tgrid, cell);
     const int col = cell - a.tgrid.off[band];
     const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
     AgWindow w;
@@ -447,7 +440,7 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       for (int r = 0; r < AG_WIN_RANGES; ++r)
         if (r < win.d[0]) stage_run(win.d[1 + 2 * r], win.d[2 + 2 * r]);
     } else {
-      const int band = a.tband[cell];
+      const int band = ag_band_of_cell(a.tgrid, cell);
       const int col = cell - a.tgrid.off[band];
       const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
       ag_cell_window(a.sgrid, a.sstart, band, col * wlon, (col + 1) * wlon, stage_run);
@@ -817,7 +810,6 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.sstart = w.src.cell_start;
   a.tids = w.tgt.ids;
   a.tstart = w.tgt.cell_start;
-  a.tband = w.tgt.cell_band;
   a.tgt = reinterpret_cast<const float2*>(d_tgt);
   a.src = reinterpret_cast<const float2*>(d_src);
   a.ns = ns;
