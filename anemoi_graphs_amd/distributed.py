@@ -49,41 +49,63 @@ class Communicator:
         self.dist.all_gather(out, mine)
         return torch.stack(out).cpu()
 
-    def all_gather_rows(self, t: torch.Tensor, dim: int = 0, counts: list[int] | None = None) -> torch.Tensor:
-        """Concatenate variable-length chunks of every rank along ``dim`` in rank order."""
-        return self.all_gather_rows_async(t, dim, counts)()
+    def all_gather_rows(self, t: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
+        """Concatenate variable-length chunks [n_r, ...] of every rank along dim 0 in rank order."""
+        return self.all_gather_rows_async([t], counts)()[0]
 
-    def all_gather_rows_async(self, t: torch.Tensor, dim: int = 0, counts: list[int] | None = None):
-        """Start the variable-length all-gather of ``t`` along ``dim``; the returned callable waits for
-        it and gives the concatenation in rank order.  ``counts`` (the chunk length of every rank)
-        saves the size exchange when the caller knows them."""
-        device = t.device
-        t = t.movedim(dim, 0).contiguous()
+    def all_gather_rows_async(self, parts: list[torch.Tensor], counts: list[int] | None = None,
+                              out: list[torch.Tensor] | None = None):
+        """Start one all-gather per tensor of ``parts`` (all with the same, per-rank variable, length
+        along dim 0); the returned callable waits for them and gives the list of concatenations in rank
+        order.  ``counts`` (the chunk length of every rank) saves the size exchange when the caller knows
+        them.  When every rank holds the same number of rows the chunks land directly in their final
+        place (``out[i]`` if given, e.g. a row of an edge_index): no padding, no second copy."""
+        device = parts[0].device
+        n = parts[0].shape[0]
         if counts is None:
-            counts = self.all_gather_sizes([t.shape[0]], device)[:, 0].tolist()
-        width = max(counts)
-        if t.shape[0] == width:
-            padded = t
-        else:
-            padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            padded[: t.shape[0]] = t
-        padded = self._out(padded)
-        chunks = [torch.empty_like(padded) for _ in range(self.world)]
-        work = self.dist.all_gather(chunks, padded, async_op=True)
+            counts = self.all_gather_sizes([n], device)[:, 0].tolist()
+        width, total = max(counts), sum(counts)
+        equal = total == width * self.world
+        stage = "cpu" if self.host_staged else device
+        works, gathered, keep = [], [], []
+        for i, t in enumerate(parts):
+            t = t.contiguous()
+            if n != width:
+                padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                padded[:n] = t
+                t = padded
+            t = self._out(t)
+            direct = equal and not self.host_staged and out is not None
+            buf = out[i] if direct else torch.empty((self.world * width,) + tuple(t.shape[1:]), dtype=t.dtype,
+                                                    device=stage)
+            works.append(self.dist.all_gather_into_tensor(buf, t, async_op=True))
+            gathered.append(buf)
+            keep.append(t)
 
-        def finish() -> torch.Tensor:
-            work.wait()
-            out = torch.cat([c[:n] for c, n in zip(chunks, counts)], dim=0)
-            return self._back(out, device).movedim(0, dim).contiguous()
+        def finish() -> list[torch.Tensor]:
+            for w in works:
+                w.wait()
+            res = []
+            for i, buf in enumerate(gathered):
+                dst = out[i] if out is not None else None
+                if dst is None and equal:
+                    dst = self._back(buf, device)
+                elif dst is None or dst.data_ptr() != buf.data_ptr():
+                    if dst is None:
+                        dst = torch.empty((total,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=device)
+                    off = 0
+                    for r, c in enumerate(counts):  # drop the padding of the shorter chunks
+                        dst[off: off + c].copy_(buf[r * width: r * width + c])
+                        off += c
+                res.append(dst)
+            keep.clear()
+            return res
 
         return finish
 
-    def exchange_halo(self, to_north: torch.Tensor, to_south: torch.Tensor):
-        """Send rows to the two neighbours, receive theirs: returns (from_north, from_south)."""
+    def exchange_halo(self, to_north: torch.Tensor, to_south: torch.Tensor, n_from_north: int, n_from_south: int):
+        """Send rows to the two neighbours, receive theirs (``n_from_*`` rows): returns (from_north, from_south)."""
         device = to_north.device
-        sizes = self.all_gather_sizes([to_north.shape[0], to_south.shape[0]], device)
-        n_from_north = int(sizes[self.rank - 1, 1]) if self.rank > 0 else 0
-        n_from_south = int(sizes[self.rank + 1, 0]) if self.rank < self.world - 1 else 0
         recv_dev = "cpu" if self.host_staged else device
         from_north = torch.empty((n_from_north, 2), dtype=to_north.dtype, device=recv_dev)
         from_south = torch.empty((n_from_south, 2), dtype=to_north.dtype, device=recv_dev)
@@ -135,16 +157,20 @@ class ShardedGraphBuilder:
         self.data_full = data_x if world_size == 1 else None
         self.data_all = data_x  # every rank is given the complete coordinate array (53 MB for O1280)
         self.data_local = data_x[lo:hi].contiguous()
-        if world_size > 1:
+        if world_size > 1 or dist is not None:  # (a process group of one rank still takes the sharded route)
             lat = self.data_local[:, 0]
             if lat.numel() > 1 and bool((lat[1:] > lat[:-1]).any()):
                 raise ValueError("latitude-band sharding needs data nodes ordered north -> south")
             self.comm = Communicator(dist, rank, world_size)
             # cut latitudes: the first latitude of every band (band r holds lat <= cut[r])
-            firsts = self.comm.all_gather_rows(self.data_local[:1, 0].reshape(1, 1))
-            lasts = self.comm.all_gather_rows(self.data_local[-1:, 0].reshape(1, 1))
-            self.first_lat = firsts.reshape(-1).cpu().tolist()
-            self.last_lat = lasts.reshape(-1).cpu().tolist()
+            ends = self.comm.all_gather_rows(self.data_local[[0, -1], 0].reshape(1, 2), counts=[1] * world_size)
+            self.first_lat = ends[:, 0].cpu().tolist()
+            self.last_lat = ends[:, 1].cpu().tolist()
+            # search keys of the band limits, kept on the device (ascending = negated latitudes)
+            dev = self.data_local.device
+            self.neg_lat = (-self.data_local[:, 0]).contiguous()
+            self.neg_upper = torch.tensor(-self.first_lat[rank], dtype=lat.dtype, device=dev)
+            self.neg_lower = torch.tensor(-self.first_lat[min(rank + 1, world_size - 1)], dtype=lat.dtype, device=dev)
         else:
             self.comm = None
 
@@ -193,58 +219,55 @@ class ShardedGraphBuilder:
         nh = hidden.shape[0]
 
         # ---- encoder: hidden targets of my band, data sources = my band + halo
-        radius = float(be.nn_maxdist(hidden).item()) * self.cutoff_factor
-        pad = radius * 1.0e-6 + 1.0e-7
-        reach = radius + pad
-        hlat = hidden[:, 0].contiguous()
+        # (band limits by binary search on the device; one host synchronisation for all of them)
+        radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
+        reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-7
+        nd = self.data_local.shape[0]
+        neg_hlat = (-hidden[:, 0]).contiguous()
+        zero = torch.zeros((), dtype=torch.int64, device=dev)
         # hidden nodes are latitude-descending: band r = lat in (first_lat[r+1], first_lat[r]]
-        upper = float("inf") if r == 0 else self.first_lat[r]
-        lower = -float("inf") if r == W - 1 else self.first_lat[r + 1]
-        neg = (-hlat).cpu()
-        h_lo = int(torch.searchsorted(neg, torch.tensor(-upper, dtype=neg.dtype), right=False)) if r > 0 else 0
-        h_hi = int(torch.searchsorted(neg, torch.tensor(-lower, dtype=neg.dtype), right=False)) if r < W - 1 else nh
+        h_lo = torch.searchsorted(neg_hlat, self.neg_upper.to(neg_hlat.dtype)) if r > 0 else zero
+        h_hi = torch.searchsorted(neg_hlat, self.neg_lower.to(neg_hlat.dtype)) if r < W - 1 else zero + nh
         # rows my neighbours need from me: their hidden band widened by the reach
-        my_lat_neg = (-self.data_local[:, 0]).cpu()
-        one_hop = True
-        if r > 0:
-            # the north neighbour's targets reach down to first_lat[r] - reach
-            n_north = int(torch.searchsorted(my_lat_neg, torch.tensor(-(self.first_lat[r] - reach), dtype=my_lat_neg.dtype), right=True))
-            one_hop = one_hop and n_north < self.data_local.shape[0]
+        if r > 0:  # the north neighbour's targets reach down to first_lat[r] - reach
+            q = (-(self.first_lat[r] - reach_t)).to(self.neg_lat.dtype)
+            n_north = torch.searchsorted(self.neg_lat, q, right=True)
         else:
-            n_north = 0
-        if r < W - 1:
-            # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
-            s_start = int(torch.searchsorted(my_lat_neg, torch.tensor(-(self.first_lat[r + 1] + reach), dtype=my_lat_neg.dtype), right=False))
-            one_hop = one_hop and s_start > 0
+            n_north = zero
+        if r < W - 1:  # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
+            q = (-(self.first_lat[r + 1] + reach_t)).to(self.neg_lat.dtype)
+            s_start = torch.searchsorted(self.neg_lat, q, right=False)
         else:
-            s_start = self.data_local.shape[0]
-        flags = comm.all_gather_sizes([int(one_hop)], dev)[:, 0]
-        if bool(flags.min()):
-            from_north, from_south = comm.exchange_halo(self.data_local[:n_north], self.data_local[s_start:])
-            sources = torch.cat([from_north, self.data_local, from_south], dim=0).contiguous()
+            s_start = zero + nd
+        vals = torch.stack([radius_t] + [v.reshape(()).double() for v in (h_lo, h_hi, n_north, s_start)]).tolist()
+        radius = vals[0]
+        h_lo, h_hi, n_north, s_start = (int(v) for v in vals[1:])
+        one_hop = (r == 0 or n_north < nd) and (r == W - 1 or s_start > 0)
+        sizes = comm.all_gather_sizes([int(one_hop), n_north, nd - s_start], dev)
+        if bool(sizes[:, 0].min()):
+            from_north, from_south = comm.exchange_halo(
+                self.data_local[:n_north], self.data_local[s_start:],
+                int(sizes[r - 1, 2]) if r > 0 else 0, int(sizes[r + 1, 1]) if r < W - 1 else 0)
+            sources = torch.cat([from_north, self.data_local, from_south], dim=0) if W > 1 else self.data_local
             g_lo = self.d_lo - from_north.shape[0]
         else:  # radius wider than a band: every rank takes all data rows
             sources = comm.all_gather_rows(self.data_local)
             g_lo = 0
         targets = hidden[h_lo:h_hi].contiguous()
         enc = be.radius_edges(sources, targets, radius)
-        enc = enc.clone()
         enc[0] += g_lo
         enc[1] += h_lo
-        enc_gather = comm.all_gather_rows_async(enc, dim=1)
+        enc_counts = comm.all_gather_sizes([enc.shape[1]], dev)[:, 0].tolist()
+        enc_all = torch.empty((2, sum(enc_counts)), dtype=enc.dtype, device=dev)
+        enc_gather = comm.all_gather_rows_async([enc[0], enc[1]], enc_counts, out=[enc_all[0], enc_all[1]])
 
-        # ---- decoder: my data band as targets, replicated hidden sources
-        nt = self.data_local.shape[0]
-        if hasattr(be, "knn_edges"):
-            dec = be.knn_edges(hidden, self.data_local, self.k)
-        else:
-            ids = be.knn(hidden, self.data_local, self.k)
-            dec = torch.empty((2, nt * self.k), dtype=torch.int32, device=ids.device)
-            dec[0] = ids.reshape(-1)
-            dec[1] = torch.arange(nt, dtype=torch.int32, device=ids.device).repeat_interleave(self.k)
-        dec[1] += self.d_lo
+        # ---- decoder: my data band as targets, replicated hidden sources; only the source ids travel
+        # (the target row of a k-NN edge list is 0,0,0,1,1,1,... whatever the band)
+        ids = be.knn(hidden, self.data_local, self.k).reshape(-1)
         band_sizes = [(self.bounds[i + 1] - self.bounds[i]) * self.k for i in range(W)]
-        dec_gather = comm.all_gather_rows_async(dec, dim=1, counts=band_sizes)
+        dec_all = torch.empty((2, self.n_data * self.k), dtype=torch.int32, device=dev)
+        dec_gather = comm.all_gather_rows_async([ids], band_sizes, out=[dec_all[0]])
+        dec_all[1] = be.row_ids(self.n_data, self.k, dev)
 
         # ---- processor: replicated, while the edge lists travel
         proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,
@@ -259,11 +282,11 @@ class ShardedGraphBuilder:
             self._finish_attrs(graph[name], *self._attrs(hidden, hidden, proc))
 
         # ---- the complete edge lists; attributes on them (same kernels and inputs as a single-GPU build)
-        for name, gather, src_x, tgt_x, etype in (
-            (("data", "to", "hidden"), enc_gather, data_all, hidden, "CutOffEdges"),
-            (("hidden", "to", "data"), dec_gather, hidden, data_all, "KNNEdges"),
+        for name, gather, edge_index, src_x, tgt_x, etype in (
+            (("data", "to", "hidden"), enc_gather, enc_all, data_all, hidden, "CutOffEdges"),
+            (("hidden", "to", "data"), dec_gather, dec_all, hidden, data_all, "KNNEdges"),
         ):
-            edge_index = gather()
+            gather()
             graph[name].edge_index = edge_index
             graph[name].edge_type = etype
             if self.attributes:
@@ -271,7 +294,7 @@ class ShardedGraphBuilder:
         return graph
 
     def build(self) -> HeteroData:
-        if self.world == 1:
+        if self.comm is None:
             with settings.resident(settings.device_resident):
                 return self._build_single()
         return self._build_sharded()

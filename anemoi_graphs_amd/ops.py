@@ -94,6 +94,16 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int) -> torch.Tensor:
     return edge_index
 
 
+def row_ids(rows: int, k: int, device: torch.device) -> torch.Tensor:
+    """int32 [rows*k]: 0 (k times), 1 (k times), ... -- the target row of a k-NN edge list."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        out = torch.empty(rows * k, dtype=torch.int32, device=dev)
+        _lib.check(lib.ag_fill_row_ids(_ptr(out), rows, k, _stream(dev)), "ag_fill_row_ids")
+    return out
+
+
 def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
     """0-dim float64 device tensor: max over the nodes of the distance to the nearest other node."""
     lib = _lib.load()

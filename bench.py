@@ -125,6 +125,11 @@ def main() -> None:
                     help="which kernel launches carry HIP events inside the timed region")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: whatever libraries write to file descriptor 1
+    # (RCCL prints a version banner there when the first communicator is created) goes to stderr
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -138,8 +143,15 @@ def main() -> None:
     backend = os.environ.get("AG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # AG_BENCH_FORCE_DIST=1: a process group even for one rank, so that a one-GPU machine runs the
+    # sharded route (collectives of one rank) instead of the plain single-GPU sequence
+    if world > 1 or os.environ.get("AG_BENCH_FORCE_DIST"):
         import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -248,7 +260,8 @@ def main() -> None:
     if not args.no_cpu_baseline and world == 1:
         hidden_np = graph["hidden"].x.cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(data_np, hidden_np)
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(line_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -37,6 +37,10 @@ def knn(src, tgt, k):
     return torch.from_numpy(e[0].reshape(len(_np(tgt)), k).copy())
 
 
+def row_ids(rows, k, device=None):
+    return torch.arange(rows, dtype=torch.int32).repeat_interleave(k)
+
+
 def multiscale_edges(max_resolution, levels, x_hops, rank, level_edges=None, active=None):
     rank = _np(rank)
     order = np.empty_like(rank)

@@ -1,5 +1,6 @@
-"""GPU, two processes sharing the one GPU over gloo (tensors staged through host memory): the
-latitude-band sharded build with the HIP kernels yields exactly the single-process graph."""
+"""GPU, two or three processes sharing the one GPU over gloo (tensors staged through host memory), and one
+process over RCCL with device tensors: the latitude-band sharded build with the HIP kernels yields exactly the
+single-process graph."""
 import os
 import socket
 
@@ -32,12 +33,16 @@ def _dump(g, path):
     np.savez(path, **out)
 
 
-def _worker(rank, world, port, grid, resolution, factor, out_dir):
+def _worker(rank, world, port, grid, resolution, factor, out_dir, backend="gloo"):
     from anemoi_graphs_amd import settings
     from anemoi_graphs_amd.distributed import ShardedGraphBuilder
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
         data = torch.from_numpy(grids.named(grid)).to("cuda:0")
@@ -50,13 +55,17 @@ def _worker(rank, world, port, grid, resolution, factor, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grid,resolution,factor,world", [("o96", 4, 0.6, 2), ("o320", 5, 0.6, 3), ("o96", 3, 3.0, 2)])
-def test_sharded_hip_build_equals_single(device, tmp_path, grid, resolution, factor, world):
+@pytest.mark.parametrize("grid,resolution,factor,world,backend", [
+    ("o96", 4, 0.6, 2, "gloo"), ("o320", 5, 0.6, 3, "gloo"), ("o96", 3, 3.0, 2, "gloo"),
+    # RCCL with device tensors: one rank only, two ranks cannot share the one GPU of the test machine
+    ("o320", 5, 0.6, 1, "nccl"),
+])
+def test_sharded_hip_build_equals_single(device, tmp_path, grid, resolution, factor, world, backend):
     from anemoi_graphs_amd import settings
     from anemoi_graphs_amd.distributed import ShardedGraphBuilder
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path), backend), nprocs=world, join=True)
     data = torch.from_numpy(grids.named(grid)).to(device)
     single = ShardedGraphBuilder(data, resolution, cutoff_factor=factor, num_nearest_neighbours=3, x_hops=1,
                                  edge_length_norm="unit-max", edge_direction_norm="unit-std")
