@@ -49,9 +49,22 @@ __device__ __forceinline__ double ag_rsqrt_f64(double x) {
 // sqrt(x) for x >= 0 (normal or zero)
 __device__ __forceinline__ double ag_sqrt_f64(double x) { return x > 0.0 ? x * ag_rsqrt_f64(x) : 0.0; }
 
+// Coefficients of the arctangent polynomial, highest degree first.  They are passed to the kernel as
+// an argument so that they live in scalar registers: a float64 literal cannot be an instruction
+// operand, and a vector register pair per coefficient would have to be reloaded for every term.
+struct AgAtanCoef {
+  double q[17];
+};
+static const AgAtanCoef AG_ATAN_COEF = {{
+    -0x1.116cf4eed9ee2p-14, 0x1.478bc19252cd1p-11, -0x1.7239c656c970bp-9, 0x1.090411c9f7d90p-7,
+    -0x1.11a34bdf175c0p-6, 0x1.bb63244527d8fp-6, -0x1.2e09b36d6dd7ep-5, 0x1.705f0bf9c30f1p-5,
+    -0x1.a871f31487e16p-5, 0x1.e0520791dacd2p-5, -0x1.10ef041012eacp-4, 0x1.3b0f9b9c5c124p-4,
+    -0x1.745cc3b58ce48p-4, 0x1.c71c6db0fec78p-4, -0x1.24924917024dcp-3, 0x1.9999999975b97p-3,
+    -0x1.55555555554d6p-2}};
+
 // atan2(y, x) for y, x >= 0, not both zero; NaN if either is NaN.  atan(t) = t + t s Q(s), s = t^2,
 // on t = min/max in [0, 1]; Q interpolates (atan(t)/t - 1)/s at 17 Chebyshev nodes (tools/fit_atan.py).
-__device__ __forceinline__ double ag_atan2_pos(double y, double x) {
+__device__ __forceinline__ double ag_atan2_pos(double y, double x, const AgAtanCoef& K) {
   const double hi = fmax(x, y), lo = fmin(x, y);
   double r = __builtin_amdgcn_rcp(hi);
   double e = __builtin_fma(-hi, r, 1.0);
@@ -61,23 +74,9 @@ __device__ __forceinline__ double ag_atan2_pos(double y, double x) {
   double t = lo * r;
   t = __builtin_fma(__builtin_fma(-hi, t, lo), r, t);
   const double s = t * t;
-  double p = -0x1.116cf4eed9ee2p-14;
-  p = __builtin_fma(p, s, 0x1.478bc19252cd1p-11);
-  p = __builtin_fma(p, s, -0x1.7239c656c970bp-9);
-  p = __builtin_fma(p, s, 0x1.090411c9f7d90p-7);
-  p = __builtin_fma(p, s, -0x1.11a34bdf175c0p-6);
-  p = __builtin_fma(p, s, 0x1.bb63244527d8fp-6);
-  p = __builtin_fma(p, s, -0x1.2e09b36d6dd7ep-5);
-  p = __builtin_fma(p, s, 0x1.705f0bf9c30f1p-5);
-  p = __builtin_fma(p, s, -0x1.a871f31487e16p-5);
-  p = __builtin_fma(p, s, 0x1.e0520791dacd2p-5);
-  p = __builtin_fma(p, s, -0x1.10ef041012eacp-4);
-  p = __builtin_fma(p, s, 0x1.3b0f9b9c5c124p-4);
-  p = __builtin_fma(p, s, -0x1.745cc3b58ce48p-4);
-  p = __builtin_fma(p, s, 0x1.c71c6db0fec78p-4);
-  p = __builtin_fma(p, s, -0x1.24924917024dcp-3);
-  p = __builtin_fma(p, s, 0x1.9999999975b97p-3);
-  p = __builtin_fma(p, s, -0x1.55555555554d6p-2);
+  double p = K.q[0];
+#pragma unroll
+  for (int i = 1; i < 17; ++i) p = __builtin_fma(p, s, K.q[i]);
   const double at = __builtin_fma(t * s, p, t);
   double res = (y > x) ? (AG_HALF_PI - at) : at;
   if (x != x || y != y) res = x + y;
@@ -105,36 +104,38 @@ __device__ __forceinline__ void ag_attr_target(float2 tp, bool rotated, AgAttrRu
   const double eps = 10e-11;
   // axis = target x pole, angle = acos(target . pole)
   double vx = static_cast<double>(tyf), vy = -static_cast<double>(txf);
-  double n2 = vx * vx + vy * vy;
+  double n2 = __builtin_fma(vx, vx, vy * vy);
   if (n2 < eps) {  // target at a pole: the reference nudges the float32 point in place
     txf = txf + eps32;
     tyf = tyf + eps32;
     tzf = tzf + eps32;
     vx = static_cast<double>(tyf);
     vy = -static_cast<double>(txf);
-    n2 = vx * vx + vy * vy;
+    n2 = __builtin_fma(vx, vx, vy * vy);
   }
-  // scipy builds the unit quaternion (axis * sin(theta/2), cos(theta/2)) from the rotation vector
-  // axis * theta with theta = acos(z).  Since cos(theta) = z by definition, the half-angle identities
-  // give the same quaternion without inverse trigonometry: sin(theta/2) = sqrt((1-z)/2),
-  // cos(theta/2) = sqrt((1+z)/2); 1 -/+ z are exact in float64 for a float32 z.
+  // scipy builds the unit quaternion q = (u sin(theta/2), cos(theta/2)), u = axis / |axis|, from the
+  // rotation vector u theta with theta = acos(z), and from it the matrix.  With qz = 0 and the
+  // half-angle identities sin^2(theta/2) = (1-z)/2, cos^2(theta/2) = (1+z)/2, 2 sin cos = sin(theta)
+  // the matrix rows 0 and 1 need one reciprocal root (|axis|) and one root (sin(theta)), no inverse
+  // trigonometry; 1 -/+ z are exact in float64 for a float32 z.
   const double inv_norm = ag_rsqrt_f64(n2);
+  const double ux = vx * inv_norm, uy = vy * inv_norm;
   const double z = static_cast<double>(tzf);
-  const double sh = ag_sqrt_f64(0.5 * (1.0 - z)), ch = ag_sqrt_f64(0.5 * (1.0 + z));
-  const double qx = (vx * inv_norm) * sh, qy = (vy * inv_norm) * sh, qw = ch;  // qz = 0
-  // scipy Rotation.as_matrix, rows 0 and 1, with qz = 0 (m10 = m01)
-  const double x2 = qx * qx, y2 = qy * qy, w2 = qw * qw;
-  R.m00[r] = x2 - y2 + w2;
-  R.m01[r] = 2.0 * (qx * qy);
-  R.m02[r] = 2.0 * (qy * qw);
-  R.m11[r] = -x2 + y2 + w2;
-  R.m12[r] = -2.0 * (qx * qw);
+  const double omz = 1.0 - z, opz = 1.0 + z;
+  const double sin_t = ag_sqrt_f64(omz * opz);
+  const double a = 0.5 * omz, b = 0.5 * opz;
+  const double d = a * __builtin_fma(ux, ux, -(uy * uy));
+  R.m00[r] = b + d;
+  R.m11[r] = b - d;
+  R.m01[r] = (ux * uy) * omz;
+  R.m02[r] = uy * sin_t;
+  R.m12[r] = -(ux * sin_t);
 }
 
 // One edge: utils.haversine_distance (utils.py:99-103) in float32 and the direction of the
 // rotated source with respect to the pole (edges/directional.py:68-94).
 __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int r, bool rotated, bool want_len,
-                                             bool want_dir, float* len, float2* dir) {
+                                             bool want_dir, const AgAtanCoef& K, float* len, float2* dir) {
   const float tlat = R.lat[r], tlon = R.lon[r];
   float ss, cs;
   ag_np_sincos_f32(sp.x, &ss, &cs);
@@ -146,7 +147,7 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
     const float s1 = ag_np_sin_f32(dlon / 2.0f);
     const float a = s0 * s0 + cs * ct * (s1 * s1);
     const float y = sqrtf(a), x = sqrtf(1.0f - a);
-    *len = 2.0f * static_cast<float>(ag_atan2_pos(static_cast<double>(y), static_cast<double>(x)));
+    *len = 2.0f * static_cast<float>(ag_atan2_pos(static_cast<double>(y), static_cast<double>(x), K));
   }
   if (want_dir) {
     if (!rotated) {
@@ -157,17 +158,17 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
     ag_np_sincos_f32(sp.y, &so, &co);
     const double sx = static_cast<double>(cs * co), sy = static_cast<double>(cs * so), sz = static_cast<double>(ss);
     const double m01 = R.m01[r];
-    double px = R.m00[r] * sx + m01 * sy + R.m02[r] * sz;
-    double py = m01 * sx + R.m11[r] * sy + R.m12[r] * sz;
+    double px = __builtin_fma(R.m00[r], sx, __builtin_fma(m01, sy, R.m02[r] * sz));
+    double py = __builtin_fma(m01, sx, __builtin_fma(R.m11[r], sy, R.m12[r] * sz));
     const double eps = 10e-11;
     double dx = py, dy = -px;
-    double m2 = dx * dx + dy * dy;
+    double m2 = __builtin_fma(dx, dx, dy * dy);
     if (m2 < eps) {
       px += eps;
       py += eps;
       dx = py;
       dy = -px;
-      m2 = dx * dx + dy * dy;
+      m2 = __builtin_fma(dx, dx, dy * dy);
     }
     const double inv = ag_rsqrt_f64(m2);
     *dir = make_float2(static_cast<float>(dx * inv), static_cast<float>(dy * inv));
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
                                                             const float2* __restrict__ tgt_x,
                                                             const int32_t* __restrict__ es,
                                                             const int32_t* __restrict__ et, int64_t E, int flags,
-                                                            float* __restrict__ out_len, float2* __restrict__ out_dir) {
+                                                            float* __restrict__ out_len, float2* __restrict__ out_dir,
+                                                            const AgAtanCoef K) {
   __shared__ AgAttrRuns R_all[4];
   const bool rotated = (flags & AG_ATTR_ROTATED) != 0 && out_dir != nullptr;
   const bool want_len = out_len != nullptr, want_dir = out_dir != nullptr;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
       const int64_t e = base + j * 64 + lane;
       float len;
       float2 dir;
-      ag_attr_edge(g0.sp[j], R, run[j], rotated, want_len, want_dir, &len, &dir);
+      ag_attr_edge(g0.sp[j], R, run[j], rotated, want_len, want_dir, K, &len, &dir);
       if (want_len) out_len[e] = len;
       if (want_dir) out_dir[e] = dir;
     }
@@ -279,7 +281,7 @@ extern "C" int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tg
   AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
   if (E == 0 || (d_len == nullptr && d_dir == nullptr)) return AG_OK;
   AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
-  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, 4 * AG_ATTR_CHUNK, 256 * 8)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir));
+  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, 4 * AG_ATTR_CHUNK, 256 * 8)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), AG_ATAN_COEF);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -176,8 +176,8 @@ __device__ __forceinline__ double ag_rdist_to_dist(double r) { return 2.0 * asin
 __device__ __forceinline__ void ag_np_sincos_f32(float x, float* s_out, float* c_out) {
   const float two_over_pi = 0x1.45f306p-1f;
   const float magic = 0x1.8p+23f;
-  float q = x * two_over_pi;
-  q = (q + magic) - magic;  // round to nearest integer
+  const float qm = x * two_over_pi + magic;
+  const float q = qm - magic;  // round to nearest integer
   float r = __fmaf_rn(q, -0x1.921fb0p+00f, x);
   r = __fmaf_rn(q, -0x1.5110b4p-22f, r);
   r = __fmaf_rn(q, -0x1.846988p-48f, r);
@@ -191,12 +191,13 @@ __device__ __forceinline__ void ag_np_sincos_f32(float x, float* s_out, float* c
   cp = __fmaf_rn(cp, r2, 0x1.55553cp-05f);
   cp = __fmaf_rn(cp, r2, -0x1.000000p-01f);
   cp = __fmaf_rn(cp, r2, 1.0f);
-  const int iq = static_cast<int>(rintf(q));
-  float s = (iq & 1) ? cp : sp;
-  if (iq & 2) s = 0.0f - s;
-  const int ic = iq + 1;
-  float c = (ic & 1) ? cp : sp;
-  if (ic & 2) c = 0.0f - c;
+  // round(q) sits in the low mantissa bits of q + magic; quadrant n: sin = (n odd ? cp : sp), negated
+  // for n = 2, 3 (mod 4); cos is the same with n + 1.  (The negations are sign-bit flips: a value that
+  // is negated here is never zero.)
+  const unsigned n = __float_as_uint(qm);
+  const bool odd = (n & 1u) != 0u;
+  const float s = __uint_as_float(__float_as_uint(odd ? cp : sp) ^ ((n << 30) & 0x80000000u));
+  const float c = __uint_as_float(__float_as_uint(odd ? sp : cp) ^ (((n + 1u) << 30) & 0x80000000u));
   *s_out = s;
   *c_out = c;
 }
