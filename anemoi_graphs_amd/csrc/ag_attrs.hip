@@ -83,6 +83,20 @@ __device__ __forceinline__ double ag_atan2_pos(double y, double x, const AgAtanC
   return res;
 }
 
+// Correctly rounded float32 square root of the haversine terms (0 <= x <= 1, or x < 0 -> NaN): the
+// hardware root is within one ulp, and the exact residuals of its two neighbours (one fused
+// multiply-add each) tell which of the three is the rounded root.  Without the rescaling a library
+// sqrtf carries for x < 2^-96 (an edge shorter than 4e-15 rad), where the residuals underflow and the
+// result may be one ulp off.
+__device__ __forceinline__ float ag_sqrt_f32_rn(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+  const float rm = __fmaf_rn(-ym, y, x), rp = __fmaf_rn(-yp, y, x);
+  float r = rm <= 0.0f ? ym : y;
+  r = rp > 0.0f ? yp : r;
+  return r;
+}
+
 // Per-run (per distinct target) data staged in LDS
 struct AgAttrRuns {
   double m00[AG_ATTR_CHUNK], m01[AG_ATTR_CHUNK], m02[AG_ATTR_CHUNK], m11[AG_ATTR_CHUNK], m12[AG_ATTR_CHUNK];
@@ -146,7 +160,7 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
     const float s0 = ag_np_sin_f32(dlat / 2.0f);
     const float s1 = ag_np_sin_f32(dlon / 2.0f);
     const float a = s0 * s0 + cs * ct * (s1 * s1);
-    const float y = sqrtf(a), x = sqrtf(1.0f - a);
+    const float y = ag_sqrt_f32_rn(a), x = ag_sqrt_f32_rn(1.0f - a);
     *len = 2.0f * static_cast<float>(ag_atan2_pos(static_cast<double>(y), static_cast<double>(x), K));
   }
   if (want_dir) {
@@ -200,22 +214,29 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
   const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
   // lane l owns edges base + l and base + 64 + l.  Three chunks are in flight per wave: the ids of
   // chunk c+2 are being fetched and the endpoints of chunk c+1 gathered while chunk c is evaluated.
+  // Loads are never predicated: an index past the end of the list (or of the chunk sequence) is
+  // clamped to the last edge, whose values are loaded again and ignored.
   struct Ids {
     int t[2], s[2], p[2];
   };
   struct Ends {
     float2 sp[2], tp[2];
+    bool first[2];  // the edge starts a run of equal targets inside its chunk
   };
   auto fetch_ids = [&](int64_t chunk) {
     Ids r;
-    const int64_t base = chunk * AG_ATTR_CHUNK;
+    const int64_t c = chunk < nchunks ? chunk : nchunks - 1;
+    const int64_t base = c * AG_ATTR_CHUNK;
+    const int64_t left = E - base;
+    const int last = (left < AG_ATTR_CHUNK ? static_cast<int>(left) : AG_ATTR_CHUNK) - 1;
+    const int32_t* __restrict__ etc = et + base;
+    const int32_t* __restrict__ esc = es + base;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int64_t e = base + j * 64 + lane;
-      const bool ok = chunk < nchunks && e < E;
-      r.t[j] = ok ? et[e] : -1;
-      r.s[j] = ok ? es[e] : 0;
-      r.p[j] = (ok && e > base) ? et[e - 1] : -1;
+      const int o = min(j * 64 + lane, last);
+      r.t[j] = etc[o];
+      r.s[j] = esc[o];
+      r.p[j] = etc[max(o - 1, 0)];
     }
     return r;
   };
@@ -223,26 +244,23 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     Ends g;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bool ok = ids.t[j] >= 0;
-      g.sp[j] = ok ? src_x[ids.s[j]] : make_float2(0.f, 0.f);
-      g.tp[j] = ok ? tgt_x[ids.t[j]] : make_float2(0.f, 0.f);
+      g.sp[j] = src_x[ids.s[j]];
+      g.tp[j] = tgt_x[ids.t[j]];
+      g.first[j] = (j * 64 + lane == 0) || ids.p[j] != ids.t[j];
     }
     return g;
   };
-  Ids ids0 = fetch_ids(wave_global);
-  Ids ids1 = fetch_ids(wave_global + nwaves);
-  Ends g0 = gather(ids0);
-  for (int64_t chunk = wave_global; chunk < nchunks; chunk += nwaves) {
+  auto process = [&](int64_t chunk, const Ends& g) {
     const int64_t base = chunk * AG_ATTR_CHUNK;
-    const Ends g1 = gather(ids1);
-    const Ids ids2 = fetch_ids(chunk + 2 * nwaves);
+    const int64_t left = E - base;
+    const int count = left < AG_ATTR_CHUNK ? static_cast<int>(left) : AG_ATTR_CHUNK;
     int run[2];
     bool valid[2], first[2];
     unsigned long long bal[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      valid[j] = base + j * 64 + lane < E;
-      first[j] = valid[j] && (j * 64 + lane == 0 || ids0.p[j] != ids0.t[j]);
+      valid[j] = j * 64 + lane < count;
+      first[j] = valid[j] && g.first[j];
       bal[j] = __ballot(first[j]);
     }
     const int n0 = __popcll(bal[0]);
@@ -251,27 +269,40 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     for (int j = 0; j < 2; ++j) {
       run[j] = (j ? n0 : 0) + __popcll(bal[j] & below) + (first[j] ? 1 : 0) - 1;
       if (first[j]) {
-        R.lat[run[j]] = g0.tp[j].x;
-        R.lon[run[j]] = g0.tp[j].y;
+        R.lat[run[j]] = g.tp[j].x;
+        R.lon[run[j]] = g.tp[j].y;
       }
     }
     ag_lds_wave_sync();
     for (int r = lane; r < nruns; r += 64) ag_attr_target(make_float2(R.lat[r], R.lon[r]), rotated, R, r);
     ag_lds_wave_sync();
+    float* __restrict__ len_c = out_len + (want_len ? base : 0);
+    float2* __restrict__ dir_c = out_dir + (want_dir ? base : 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (!valid[j]) continue;
-      const int64_t e = base + j * 64 + lane;
       float len;
       float2 dir;
-      ag_attr_edge(g0.sp[j], R, run[j], rotated, want_len, want_dir, K, &len, &dir);
-      if (want_len) out_len[e] = len;
-      if (want_dir) out_dir[e] = dir;
+      ag_attr_edge(g.sp[j], R, run[j], rotated, want_len, want_dir, K, &len, &dir);
+      if (want_len) len_c[j * 64 + lane] = len;
+      if (want_dir) dir_c[j * 64 + lane] = dir;
     }
     ag_lds_wave_sync();  // the staged runs are overwritten by the next chunk
-    ids0 = ids1;
-    ids1 = ids2;
-    g0 = g1;
+  };
+  if (wave_global >= nchunks) return;
+  // two chunks per trip, so that the two sets of gathered endpoints alternate without register copies;
+  // the ids are dead once their gather is issued and the next fetch reuses their registers
+  Ids ids = fetch_ids(wave_global);
+  Ends ga = gather(ids);
+  ids = fetch_ids(wave_global + nwaves);
+  for (int64_t chunk = wave_global; chunk < nchunks; chunk += 2 * nwaves) {
+    const Ends gb = gather(ids);
+    ids = fetch_ids(chunk + 2 * nwaves);
+    process(chunk, ga);
+    if (chunk + nwaves >= nchunks) break;
+    ga = gather(ids);
+    ids = fetch_ids(chunk + 3 * nwaves);
+    process(chunk + nwaves, gb);
   }
 }
 

@@ -16,17 +16,22 @@ radius = 0.6 * float(ops.nn_maxdist(hidden).item())
 enc = ops.radius_edges(data, hidden, radius)
 
 
-def timeit(fn, n=10):
+def timeit(fn, n=40, batches=7):
+    """Median and minimum over batches of the mean time of n back-to-back calls (ms)."""
     fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    res = []
+    for _ in range(batches):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0) / n * 1e3)
+    res.sort()
+    return res[len(res) // 2], res[0]
 
 
 for name, sx, tx, e in (("decoder", hidden, data, dec), ("encoder", data, hidden, enc)):
     for wl, wd, rot in ((True, True, True), (True, False, True), (False, True, True), (False, True, False)):
-        ms = timeit(lambda: ops.edge_attrs(sx, tx, e, want_len=wl, want_dir=wd, rotated=rot))
-        print(f"{name} E={e.shape[1]} len={wl} dir={wd} rotated={rot}: {ms:.3f} ms", flush=True)
+        med, best = timeit(lambda: ops.edge_attrs(sx, tx, e, want_len=wl, want_dir=wd, rotated=rot))
+        print(f"{name} E={e.shape[1]} len={wl} dir={wd} rotated={rot}: median {med:.4f} ms, best {best:.4f} ms", flush=True)
