@@ -477,6 +477,92 @@ __global__ __launch_bounds__(256) void ag_normalise_apply_kernel(float* __restri
   if (tid < ((n - head) & 3)) v[head + 4 * n4 + tid] = apply(v[head + 4 * n4 + tid]);
 }
 
+// float64 values (node attributes): the same statistics, applied in float64 and rounded to float32
+// once, as NormaliserMixin.normalise on a float64 array followed by astype(float32) does.
+__global__ __launch_bounds__(256) void ag_reduce_partial_f64_kernel(const double* __restrict__ v, int64_t n, int pass,
+                                                                    const AgStats* __restrict__ stats,
+                                                                    AgStats* __restrict__ partial) {
+  __shared__ AgStats sh[4];
+  double sum = 0.0, sumsq = 0.0, csumsq = 0.0, vmin = 1.0e300, vmax = -1.0e300;
+  const double mean = pass ? stats->sum / static_cast<double>(n) : 0.0;
+  const int64_t tid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n; i += nthreads) {
+    const double x = v[i];
+    if (pass == 0) {
+      sum += x;
+      sumsq += x * x;
+      vmin = fmin(vmin, x);
+      vmax = fmax(vmax, x);
+    } else {
+      const double d = x - mean;
+      csumsq += d * d;
+    }
+  }
+  sum = ag_wave_sum(sum);
+  sumsq = ag_wave_sum(sumsq);
+  csumsq = ag_wave_sum(csumsq);
+  vmin = ag_wave_min(vmin);
+  vmax = ag_wave_max(vmax);
+  const int wave = threadIdx.x >> 6;
+  if (ag_lane() == 0) sh[wave] = {sum, sumsq, vmin, vmax, csumsq};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    AgStats r = sh[0];
+    for (int w = 1; w < 4; ++w) {
+      r.sum += sh[w].sum;
+      r.sumsq += sh[w].sumsq;
+      r.csumsq += sh[w].csumsq;
+      r.vmin = fmin(r.vmin, sh[w].vmin);
+      r.vmax = fmax(r.vmax, sh[w].vmax);
+    }
+    partial[blockIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void ag_normalise_apply_f64_kernel(const double* __restrict__ v, int64_t n, int norm,
+                                                                     const AgStats* __restrict__ stats,
+                                                                     float* __restrict__ out) {
+  double scale = 1.0, shift = 0.0;
+  if (norm == 1) scale = stats->sum;
+  else if (norm == 2) scale = sqrt(stats->sumsq);
+  else if (norm == 3) scale = stats->vmax;
+  else if (norm == 4) {
+    shift = stats->vmin;
+    scale = stats->vmax - shift;
+  } else if (norm == 5) {
+    scale = sqrt(stats->csumsq / static_cast<double>(n));
+    if (scale == 0.0) scale = 1.0;  // the reference leaves the values untouched when the std is 0
+  }
+  const int64_t tid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n; i += nthreads) out[i] = static_cast<float>((v[i] - shift) / scale);
+}
+
+extern "C" int ag_normalise_f64(const double* d_values, int64_t n, int norm, float* d_out, void* d_ws, size_t ws_bytes,
+                                void* stream) {
+  AG_REQUIRE(norm >= 0 && norm <= 5, "ag_normalise_f64: unknown normalisation %d", norm);
+  AG_REQUIRE(n >= 0, "ag_normalise_f64: negative size");
+  if (n == 0) return AG_OK;
+  AG_REQUIRE(d_values && d_out && d_ws, "ag_normalise_f64: null pointer");
+  if (ws_bytes < (AG_RED_BLOCKS + 2) * sizeof(AgStats) + 512)
+    return ag_fail(AG_ERR_WORKSPACE, "ag_normalise_f64: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AgCarver c(d_ws);
+  AgStats* stats = c.take<AgStats>(1);
+  AgStats* partial = c.take<AgStats>(AG_RED_BLOCKS);
+  const int nblocks = ag_blocks(n, 256 * 8, AG_RED_BLOCKS);
+  if (norm != 0) {
+    for (int pass = 0; pass < (norm == 5 ? 2 : 1); ++pass) {
+      AG_KERNEL("ag_reduce_partial_f64_kernel", ag_reduce_partial_f64_kernel, dim3(nblocks), dim3(256), s, d_values, n, pass, stats, partial);
+      AG_LAUNCH_CHECK();
+      AG_KERNEL("ag_reduce_final_kernel", ag_reduce_final_kernel, dim3(1), dim3(256), s, partial, nblocks, pass, stats);
+      AG_LAUNCH_CHECK();
+    }
+  }
+  AG_KERNEL("ag_normalise_apply_f64_kernel", ag_normalise_apply_f64_kernel, dim3(ag_blocks(n, 256 * 4, 1 << 14)), dim3(256), s, d_values, n, norm, stats, d_out);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
 extern "C" size_t ag_normalise_workspace_bytes(int64_t n) {
   (void)n;
   return (AG_RED_BLOCKS + 2) * sizeof(AgStats) + 512;

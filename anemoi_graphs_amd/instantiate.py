@@ -16,6 +16,12 @@ _ALIASES = {
     "anemoi.graphs.edges.CutOffEdges": "anemoi_graphs_amd.edges.CutOffEdges",
     "anemoi.graphs.edges.MultiScaleEdges": "anemoi_graphs_amd.edges.MultiScaleEdges",
     "anemoi.graphs.processors.RemoveUnconnectedNodes": "anemoi_graphs_amd.processors.RemoveUnconnectedNodes",
+    "anemoi.graphs.nodes.attributes.SphericalAreaWeights": "anemoi_graphs_amd.nodes.attributes.SphericalAreaWeights",
+    "anemoi.graphs.nodes.attributes.AreaWeights": "anemoi_graphs_amd.nodes.attributes.AreaWeights",
+    "anemoi.graphs.nodes.attributes.UniformWeights": "anemoi_graphs_amd.nodes.attributes.UniformWeights",
+    "anemoi.graphs.nodes.attributes.BooleanNot": "anemoi_graphs_amd.nodes.attributes.BooleanNot",
+    "anemoi.graphs.nodes.attributes.BooleanAndMask": "anemoi_graphs_amd.nodes.attributes.BooleanAndMask",
+    "anemoi.graphs.nodes.attributes.BooleanOrMask": "anemoi_graphs_amd.nodes.attributes.BooleanOrMask",
     "anemoi.graphs.edges.attributes.EdgeLength": "anemoi_graphs_amd.edges.attributes.EdgeLength",
     "anemoi.graphs.edges.attributes.EdgeDirection": "anemoi_graphs_amd.edges.attributes.EdgeDirection",
 }

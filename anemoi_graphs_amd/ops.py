@@ -334,5 +334,112 @@ def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False) -> 
     return values
 
 
+def normalise_f64(values: torch.Tensor, norm: str | None) -> torch.Tensor:
+    """Global normalisation of a float64 device tensor, evaluated in float64 and rounded to float32."""
+    if norm not in NORMS:
+        raise ValueError(
+            f"Attribute normalisation \"{norm}\" is not valid. Options are: 'l1', 'l2', 'unit-max' or 'unit-std'."
+        )
+    lib = _lib.load()
+    dev = values.device
+    assert values.dtype == torch.float64 and values.is_contiguous()
+    n = values.numel()
+    with torch.cuda.device(dev):
+        out = torch.empty(values.shape, dtype=torch.float32, device=dev)
+        ws = _workspace(lib.ag_normalise_workspace_bytes(n), dev)
+        _lib.check(lib.ag_normalise_f64(_ptr(values), n, NORMS[norm], _ptr(out), _ptr(ws), ws.numel(), _stream(dev)),
+                   "ag_normalise_f64")
+    return out
+
+
+def radius_rows(src: torch.Tensor, tgt: torch.Tensor, radius: float):
+    """CSR form of the radius query: (offsets int64 [Nt+1], source ids int32 [E]), rows sorted by source id."""
+    lib = _lib.load()
+    dev = device_of(src, tgt)
+    src, tgt = coords(src, dev), coords(tgt, dev)
+    ns, nt = src.shape[0], tgt.shape[0]
+    with torch.cuda.device(dev):
+        offsets = torch.empty(nt + 2, dtype=torch.int64, device=dev)
+        ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
+        _lib.check(
+            lib.ag_radius_count(_ptr(src), ns, _ptr(tgt), nt, float(radius), _ptr(offsets), _ptr(ws), ws.numel(),
+                                _stream(dev)),
+            "ag_radius_count",
+        )
+        num_edges, max_row = offsets[nt:].tolist()
+        ids = torch.empty(max(num_edges, 1), dtype=torch.int32, device=dev)
+        rows = torch.empty(max(num_edges, 1), dtype=torch.int32, device=dev)
+        if num_edges:
+            _lib.check(
+                lib.ag_radius_fill(_ptr(src), ns, _ptr(tgt), nt, float(radius), _ptr(offsets), num_edges, max_row,
+                                   _ptr(ids), _ptr(rows), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_radius_fill",
+            )
+    return offsets[: nt + 1], ids[:num_edges]
+
+
+# Candidates of the first pass: each node's nearest nodes, itself included.  Ten close the cells of
+# quasi-uniform grids (eight surrounding nodes and one beyond them) and keep the k-NN query on its fast path.
+VORONOI_NEIGHBOURS = 10
+
+
+def voronoi_areas(x: torch.Tensor, neighbours: int = VORONOI_NEIGHBOURS, return_stats: bool = False):
+    """float64 [N] areas of the spherical Voronoi cells of the nodes (unit sphere).
+
+    First pass: every cell is clipped by the node's nearest ``neighbours`` nodes.  Cells that are not
+    provably final after that (elongated cells of anisotropic grids) are finished from the rows of
+    radius queries around them, the radius growing until every cell's security radius fits."""
+    lib = _lib.load()
+    dev = device_of(x)
+    x = coords(x, dev)
+    n = x.shape[0]
+    if n < 4:
+        # what scipy raises in the reference for a degenerate point set (scipy/spatial/_spherical_voronoi.py)
+        raise ValueError("Rank of input points must be at least 3")
+    k = min(int(neighbours), n, 64)
+    with torch.cuda.device(dev):
+        nbr = knn(x, x, k)
+        area = torch.empty(n, dtype=torch.float64, device=dev)
+        reach = torch.empty(n, dtype=torch.float64, device=dev)
+        _lib.check(lib.ag_voronoi_areas_knn(_ptr(x), n, _ptr(nbr), k, _ptr(area), _ptr(reach), _stream(dev)),
+                   "ag_voronoi_areas_knn")
+        del nbr
+        stats = {"first_pass_open": 0, "row_passes": 0}
+        passes = 0
+        while True:
+            if bool((reach == -1.0).any()):
+                raise ValueError("Duplicate generators present.")  # scipy's message for coincident points
+            if bool((reach == -2.0).any()):
+                raise RuntimeError("voronoi_areas: a cell has more vertices than the kernel holds")
+            todo = torch.nonzero(reach > 0.0).squeeze(1)
+            if passes == 0:
+                stats["first_pass_open"] = int(todo.numel())
+            if todo.numel() == 0:
+                break
+            need = reach[todo]
+            # an unbounded cell has no radius to ask for yet: it starts from a few mean spacings and doubles
+            floor = 4.0 * math.sqrt(4.0 * math.pi / n) * (2.0 ** passes)
+            need = torch.where(torch.isfinite(need), need, torch.full_like(need, floor)).clamp(max=math.pi)
+            # one radius query per octave of requested radii, so that a few wide cells do not make
+            # every open cell search wide
+            base = float(need.min())
+            octave = torch.ceil(torch.log2(need / base)).clamp(min=0).to(torch.int64)
+            for o in torch.unique(octave).tolist():
+                sel = todo[octave == o]
+                radius = min(base * (2.0 ** o) * (1.0 + 1.0e-12), math.pi)
+                ids = sel.to(torch.int32).contiguous()
+                offsets, rows = radius_rows(x, x[sel].contiguous(), radius)
+                _lib.check(
+                    lib.ag_voronoi_areas_rows(_ptr(x), n, _ptr(ids), ids.numel(), _ptr(offsets), _ptr(rows), radius,
+                                              _ptr(area), _ptr(reach), _stream(dev)),
+                    "ag_voronoi_areas_rows",
+                )
+                if radius >= math.pi:  # every node was offered: the cell is final whatever it reports
+                    reach[sel] = torch.where(reach[sel] > 0.0, torch.zeros_like(reach[sel]), reach[sel])
+            passes += 1
+            stats["row_passes"] = passes
+    return (area, stats) if return_stats else area
+
+
 def rdist_to_dist(r: float) -> float:
     return 2.0 * math.asin(math.sqrt(r))

@@ -161,6 +161,34 @@ int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_
 size_t ag_normalise_workspace_bytes(int64_t n);
 int ag_normalise(float* d_values, int64_t n, int norm, int invert, void* d_ws, size_t ws_bytes, void* stream);
 
+/* The same normalisations of a float64 array, applied in float64 and rounded to float32 once:
+ * BaseNodeAttribute.post_process (nodes/attributes.py:45-52) = normalise(values).astype("float32").
+ * Workspace as ag_normalise. */
+int ag_normalise_f64(const double* d_values, int64_t n, int norm, float* d_out, void* d_ws, size_t ws_bytes,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Areas of the spherical Voronoi cells of a node set.
+ * Replaces SphericalVoronoi(points, radius=1).calculate_areas() in SphericalAreaWeights
+ * (nodes/attributes.py:198-205), points = latlon_rad_to_cartesian of the float32 coordinates: the
+ * area of node i is the sum over its Voronoi vertices of the solid angles |2 atan2(det(p, v_k, v_k+1),
+ * 1 + p.v_k + v_k.v_k+1 + v_k+1.p)|.  Every cell is built on its own by clipping with the
+ * half-spaces of nearby nodes, so the caller supplies candidates and learns which cells are final:
+ *  - ag_voronoi_areas_knn: d_nbr[i*K + j] = j-th nearest node of node i, nearest first (ag_knn of
+ *    the set on itself; node i itself may be listed);
+ *  - ag_voronoi_areas_rows: for the nt nodes d_ids[t], every node within `radius` (radians) of
+ *    it, in any order, as rows d_nbr[d_offsets[t] .. d_offsets[t+1]) (ag_radius_count/fill).
+ * d_area[i] receives the area and d_reach[i]: 0 = final; > 0 = angular radius within which all
+ * nodes must be offered to finish the cell (infinity: not bounded yet); -1 = another node
+ * coincides with node i (scipy raises "duplicate generators"); -2 (from _rows only) = the cell needs
+ * more than the 48 polygon vertices the kernel holds (_knn, which holds 16, reports such a cell as
+ * not final instead).  ag_voronoi_areas_rows writes entries d_ids[t] only.
+ */
+int ag_voronoi_areas_knn(const float* d_x, int64_t n, const int32_t* d_nbr, int K, double* d_area, double* d_reach,
+                         void* stream);
+int ag_voronoi_areas_rows(const float* d_x, int64_t n, const int32_t* d_ids, int64_t nt, const int64_t* d_offsets,
+                          const int32_t* d_nbr, double radius, double* d_area, double* d_reach, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Edge list utilities.
  * ag_sort_edges: canonical sort of E (source, target) pairs in place, by (target, source) when

@@ -196,6 +196,35 @@ def case_lam(ref):
     return out
 
 
+def case_area_weights(ref):
+    """SphericalAreaWeights / UniformWeights of the reference on a reduced Gaussian grid, icosphere nodes,
+    random points and an anisotropic regular grid (no pole rows: scipy refuses duplicate generators)."""
+    from oracle import reference_path as rp
+
+    lat = np.deg2rad(np.arange(87.0, -87.1, -3.0))
+    lon = np.deg2rad(np.arange(0.0, 360.0, 1.0))
+    aniso = np.stack(np.meshgrid(lat, lon, indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float32)
+    sets = {
+        "o32": grids.named("o32"),
+        "tri3": rp.tri_nodes(3)[0].astype(np.float32),
+        "random": grids.random_sphere(3000, seed=5),
+        "aniso": aniso,
+    }
+    out = {}
+    for name, x in sets.items():
+        g = _graph(ref, nodes=x)
+        out[f"{name}_x"] = x
+        for norm in NORMS:
+            tag = "none" if norm is None else norm.replace("-", "_")
+            out[f"{name}_area_{tag}"] = ref.SphericalAreaWeights(norm=norm).compute(g, "nodes").numpy()
+        # the float64 values before post-processing, for the precision of the cells themselves
+        out[f"{name}_area_raw"] = ref.SphericalAreaWeights().get_raw_values(g["nodes"])
+    g = _graph(ref, nodes=sets["o32"])
+    out["o32_uniform_l1"] = ref.UniformWeights(norm="l1").compute(g, "nodes").numpy()
+    out["o32_uniform_none"] = ref.UniformWeights().compute(g, "nodes").numpy()
+    return out
+
+
 def case_concat(ref):
     """/root/reference/tests/test_utils.py:7-18 plus a random case."""
     e1 = torch.tensor([[0, 1, 2, 3], [-1, -2, -3, -4]])
@@ -222,6 +251,7 @@ def main() -> None:
         "tri_multiscale": case_tri,
         "concat_edges": case_concat,
         "lam_stretched": case_lam,
+        "area_weights": case_area_weights,
     }
     only = set(sys.argv[1:])
     for name, fn in cases.items():

@@ -179,6 +179,11 @@ def reference():
     from anemoi.graphs.utils import concat_edges, get_grid_reference_distance, haversine_distance
     from anemoi.graphs.generate.utils import get_coordinates_ordering
 
+    from anemoi.graphs.nodes.attributes import (BooleanAndMask, BooleanNot, BooleanOrMask, SphericalAreaWeights,
+                                                UniformWeights)
+
+    ns.SphericalAreaWeights, ns.UniformWeights = SphericalAreaWeights, UniformWeights
+    ns.BooleanNot, ns.BooleanAndMask, ns.BooleanOrMask = BooleanNot, BooleanAndMask, BooleanOrMask
     ns.KNNEdges, ns.CutOffEdges, ns.MultiScaleEdges = KNNEdges, CutOffEdges, MultiScaleEdges
     ns.EdgeLength, ns.EdgeDirection, ns.TriNodes = EdgeLength, EdgeDirection, TriNodes
     ns.LimitedAreaTriNodes, ns.StretchedTriNodes = LimitedAreaTriNodes, StretchedTriNodes

@@ -168,6 +168,33 @@ def post_process(values: np.ndarray, norm: str | None, invert: bool = False) -> 
     return 1 - out if invert else out
 
 
+# ----------------------------------------------------------------------------- node attributes
+
+
+def spherical_area_weights(coords: np.ndarray, norm: str | None = None, fill_value: float = 0.0,
+                           dtype: str = "float32", raw: bool = False) -> np.ndarray:
+    """SphericalAreaWeights.get_raw_values (nodes/attributes.py:198-221) with radius 1 and centre 0, then
+    BaseNodeAttribute.post_process (:45-52).  ``raw`` returns the float64 areas before post-processing."""
+    from scipy.spatial import SphericalVoronoi
+
+    latitudes, longitudes = coords[:, 0], coords[:, 1]
+    points = _latlon_rad_to_cartesian((np.asarray(latitudes), np.asarray(longitudes)))
+    sv = SphericalVoronoi(points, 1.0, np.array([0, 0, 0]))
+    mask = np.array([bool(i) for i in sv.regions])
+    sv.regions = [region for region in sv.regions if region]
+    area_weights = sv.calculate_areas()
+    result = np.ones(points.shape[0]) * fill_value
+    result[mask] = area_weights
+    if raw:
+        return result
+    return np.asarray(normalise(result[:, np.newaxis], norm)).astype(dtype)
+
+
+def uniform_weights(num_nodes: int, norm: str | None = None, dtype: str = "float32") -> np.ndarray:
+    """UniformWeights.get_raw_values (nodes/attributes.py:85-100) + post_process."""
+    return np.asarray(normalise(np.ones(num_nodes)[:, np.newaxis], norm)).astype(dtype)
+
+
 # ----------------------------------------------------------------------------- icosahedral nodes / edges
 
 

@@ -1,6 +1,7 @@
 """CPU: host-side behaviour of the plugin classes, mirroring the reference's own tests
 (/root/reference/tests/edges/test_knn.py, test_cutoff.py, test_multiscale_edges.py,
 tests/test_normaliser.py, tests/test_create.py) where they do not need the device."""
+import numpy as np
 import pytest
 import torch
 
@@ -11,6 +12,8 @@ from anemoi_graphs_amd.edges.attributes import EdgeDirection, EdgeLength
 from anemoi_graphs_amd.hetero import HeteroData
 from anemoi_graphs_amd.instantiate import instantiate, resolve
 from anemoi_graphs_amd.nodes import LatLonNodes, TriNodes
+from anemoi_graphs_amd.nodes.attributes import (AreaWeights, BooleanAndMask, BooleanNot, BooleanOrMask,
+                                                SphericalAreaWeights, UniformWeights)
 
 
 def test_knn_init():
@@ -165,3 +168,32 @@ def test_limited_area_and_stretched_builders_construct_like_the_reference():
     assert st.global_resolution == 2 and st.resolutions == list(range(6))
     assert st.area_mask_builder.mask_attr_name == "cutout"
     assert {"resolutions", "nx_graph", "node_ordering", "area_mask_builder"} <= set(st.hidden_attributes)
+
+
+def test_boolean_node_masks():
+    """BooleanNot / BooleanAndMask / BooleanOrMask of nodes/attributes.py:271-316 (host logic)."""
+    g = HeteroData()
+    g = LatLonNodes(np.array([0.0, 10.0, 20.0, 30.0]), np.array([0.0, 1.0, 2.0, 3.0]), "n").update_graph(g, {})
+    g["n"]["a"] = torch.tensor([True, True, False, False])
+    g["n"]["b"] = torch.tensor([True, False, True, False])
+    assert BooleanNot("a").compute(g, "n").reshape(-1).tolist() == [False, False, True, True]
+    assert BooleanAndMask(["a", "b"]).compute(g, "n").reshape(-1).tolist() == [True, False, False, False]
+    assert BooleanOrMask(["a", BooleanNot("b")]).compute(g, "n").reshape(-1).tolist() == [True, True, False, True]
+    out = BooleanOrMask(["a", "b"]).compute(g, "n")
+    assert out.dtype == torch.bool and tuple(out.shape) == (4, 1)
+    g["n"]["c"] = torch.tensor([1.0, 0.0, 1.0, 0.0])
+    with pytest.raises(AssertionError):
+        BooleanNot("c").compute(g, "n")
+
+
+def test_node_attribute_constructors_and_aliases():
+    """Constructor defaults of nodes/attributes.py:38-40,185-196 and the recipe targets."""
+    a = SphericalAreaWeights()
+    assert (a.norm, a.dtype, a.radius, a.fill_value) == (None, "float32", 1.0, 0.0)
+    assert isinstance(AreaWeights(norm="l1"), SphericalAreaWeights)
+    with pytest.raises(NotImplementedError):
+        AreaWeights(flat=True)
+    assert resolve("anemoi.graphs.nodes.attributes.SphericalAreaWeights") is SphericalAreaWeights
+    assert resolve("anemoi.graphs.nodes.attributes.UniformWeights") is UniformWeights
+    assert isinstance(instantiate({"_target_": "anemoi.graphs.nodes.attributes.AreaWeights", "norm": "unit-max"}),
+                      SphericalAreaWeights)

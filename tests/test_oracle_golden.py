@@ -144,3 +144,24 @@ def test_grids():
     assert grids.regular(0.25).shape == (1038240, 2)
     x = grids.octahedral(8)
     assert np.all(np.diff(x[:, 0]) <= 0)
+
+
+@pytest.mark.parametrize("name", ["o32", "tri3", "random", "aniso"])
+def test_area_weights_oracle_matches_reference(golden, name):
+    """SphericalAreaWeights of the reference (scipy's SphericalVoronoi) against the oracle's restatement."""
+    gold = golden("area_weights")
+    x = gold[f"{name}_x"]
+    np.testing.assert_allclose(rp.spherical_area_weights(x, raw=True), gold[f"{name}_area_raw"], rtol=1e-12)
+    for norm in [None, "l1", "l2", "unit-max", "unit-range", "unit-std"]:
+        tag = "none" if norm is None else norm.replace("-", "_")
+        want = gold[f"{name}_area_{tag}"]
+        got = rp.spherical_area_weights(x, norm)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1.2e-7, atol=1e-10 if norm == "unit-range" else 0)
+
+
+def test_uniform_weights_oracle_matches_reference(golden):
+    gold = golden("area_weights")
+    n = gold["o32_x"].shape[0]
+    np.testing.assert_array_equal(rp.uniform_weights(n, "l1"), gold["o32_uniform_l1"])
+    np.testing.assert_array_equal(rp.uniform_weights(n), gold["o32_uniform_none"])
