@@ -229,6 +229,10 @@ struct AgKnnArgs {
   long long* stats;          // [4]
 };
 
+// Largest candidate list that is re-ranked in float64 by one thread (ag_knn_resolve_kernel, registers
+// only); longer lists (k > 32) go to the wave-per-target stage 2.
+#define AG_KNN_RESOLVE_CAP 34
+
 template <int CAP>
 __device__ __forceinline__ void ag_topk_insert(float (&bd)[CAP], int (&bi)[CAP], float d, int id) {
   if (d < bd[CAP - 1]) {
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     //   re-ranked  in float64 by ag_knn_resolve_kernel if c1 lies inside the list,
     //   queued     for stage 2 if the cluster may run past the list or the k-th entry is not provably
     //              inside the region the tile covers.
-    constexpr bool RESOLVE = (CAP <= 12);
+    constexpr bool RESOLVE = (CAP <= AG_KNN_RESOLVE_CAP);
     float dk = 3.0e38f;
     int ik = -1;
 #pragma unroll
@@ -763,9 +767,9 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* queue = c.take<int>(nt);
   int* queue_count = c.take<int>(4);
   unsigned long long* max_bits = c.take<unsigned long long>(2);
-  int* cand_n = cap <= 12 ? c.take<int>(nt) : nullptr;
-  int* cand_t = cap <= 12 ? c.take<int>(nt) : nullptr;
-  int* cand_ids = cap <= 12 ? c.take<int>(nt * cap) : nullptr;
+  int* cand_n = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
+  int* cand_t = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
+  int* cand_ids = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt * cap) : nullptr;
   AgWindow* windows = c.take<AgWindow>(ag_grid_cells_ub(nb, tmult) + 1);
   if (w) {
     w->windows = windows;
@@ -784,7 +788,7 @@ template <int CAP>
 static void ag_launch_stage1(const AgKnnArgs& a, int64_t tcells_ub, hipStream_t stream) {
   const int blocks = ag_blocks(tcells_ub, AG_WAVES_PER_BLOCK);
   AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
-  if constexpr (CAP <= 12) {
+  if constexpr (CAP <= AG_KNN_RESOLVE_CAP) {
     AG_KERNEL("ag_knn_resolve_kernel", ag_knn_resolve_kernel<CAP>, dim3(ag_blocks(a.nt, 256, 8192)), dim3(256), stream, a);
   }
 }

@@ -28,7 +28,7 @@ def _knn_case(src, tgt, k, device):
     return res, stats.cpu().numpy()
 
 
-@pytest.mark.parametrize("k", [1, 3, 8, 20])
+@pytest.mark.parametrize("k", [1, 3, 8, 12, 16, 20, 32, 40])
 def test_knn_random(device, k):
     src, tgt = grids.random_sphere(3000, seed=11), grids.random_sphere(20000, seed=12)
     res, stats = _knn_case(src, tgt, k, device)
