@@ -212,6 +212,167 @@ int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream) {
   return AG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-launch exclusive scan (chained tiles with decoupled look-back).
+//
+// Tiles take a ticket when they start, so a tile only ever waits for tiles that are already
+// running, and those wait for nothing but their own data: every wait ends.  A tile publishes its
+// aggregate, then looks back over its predecessors 64 at a time (one per lane of its first wave)
+// until it meets an inclusive prefix, and publishes its own inclusive prefix.  One 64-bit word per
+// tile carries flag (top two bits: 0 empty, 1 aggregate, 2 inclusive prefix) and value together, so
+// a reader can never see one without the other.
+//
+// The state words -- AG_SCAN_HEADER + number of tiles -- must be ZERO when the kernel starts; the
+// callers have a kernel upstream that clears them along with its own counters, which is what makes
+// this one launch instead of an initialisation launch plus a scan launch.
+// out[n] receives the total; with want_max, out[n + 1] the largest input value.  in == out is allowed.
+// ---------------------------------------------------------------------------------------------
+#define AG_SCAN_HEADER 8  // [0] ticket, [1] tiles finished, [2] running maximum
+
+template <class T>
+struct AgScanTile;
+template <>
+struct AgScanTile<int> {
+  static constexpr int ITEMS = 16;
+};
+template <>
+struct AgScanTile<int64_t> {
+  static constexpr int ITEMS = 8;
+};
+
+template <class T>
+static int64_t ag_scan_tiles(int64_t n) {
+  const int64_t tile = 256 * AgScanTile<T>::ITEMS;
+  return n > 0 ? (n + tile - 1) / tile : 1;
+}
+
+size_t ag_chained_scan_state_words_i32(int64_t n) { return AG_SCAN_HEADER + ag_scan_tiles<int>(n); }
+size_t ag_chained_scan_state_words_i64(int64_t n) { return AG_SCAN_HEADER + ag_scan_tiles<int64_t>(n); }
+
+// Tile states are written with an atomic exchange and read with device-scope atomic loads; a reader that
+// has polled many times without seeing a value switches to a read-modify-write atomic, which is
+// performed where every compute die of the device sees the same value whatever a cache may hold.
+__device__ __forceinline__ unsigned long long ag_scan_state_load(unsigned long long* p, int polls) {
+  if (polls < 256) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_or(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ag_scan_state_store(unsigned long long* p, unsigned long long v) {
+  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* out, int64_t n,
+                                                              unsigned long long* __restrict__ state, int want_max) {
+  constexpr int ITEMS = AgScanTile<T>::ITEMS;
+  constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_PREFIX = 2ull << 62, VALUE = (1ull << 62) - 1ull;
+  __shared__ unsigned s_tile;
+  __shared__ long long s_wave[4];
+  __shared__ long long s_prefix;
+  __shared__ long long s_max[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(reinterpret_cast<unsigned*>(state), 1u);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int64_t ntiles = (n + 256 * ITEMS - 1) / (256 * ITEMS);
+  const int64_t first = tile * (256 * ITEMS) + int64_t(tid) * ITEMS;
+  long long v[ITEMS];
+  long long sum = 0, mx = 0;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    v[i] = (first + i < n) ? static_cast<long long>(in[first + i]) : 0;
+    sum += v[i];
+    mx = v[i] > mx ? v[i] : mx;
+  }
+  // exclusive scan of the per-thread sums inside the block
+  long long inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  if (want_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long other = __shfl_xor(mx, o, 64);
+      mx = other > mx ? other : mx;
+    }
+    if (lane == 0) s_max[wave] = mx;
+  }
+  __syncthreads();
+  long long wave_base = 0, block_total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) wave_base += s_wave[w];
+    block_total += s_wave[w];
+  }
+  const long long thread_excl = wave_base + inc - sum;
+
+  if (wave == 0) {
+    long long prefix = 0;
+    if (tile > 0) {
+      if (lane == 0) ag_scan_state_store(state + AG_SCAN_HEADER + tile, FLAG_AGG | static_cast<unsigned long long>(block_total));
+      int64_t look = tile - 1;
+      while (true) {
+        const int64_t idx = look - lane;  // lane 0 reads the nearest predecessor
+        int polls = 0;
+        unsigned long long st = idx >= 0 ? ag_scan_state_load(state + AG_SCAN_HEADER + idx, polls) : FLAG_PREFIX;
+        while (__any((st >> 62) == 0ull)) {
+          __builtin_amdgcn_s_sleep(1);
+          ++polls;
+          if (idx >= 0 && (st >> 62) == 0ull) st = ag_scan_state_load(state + AG_SCAN_HEADER + idx, polls);
+        }
+        const unsigned long long has_prefix = __ballot((st >> 62) == 2ull);
+        const int stop = has_prefix ? (__ffsll(static_cast<long long>(has_prefix)) - 1) : 64;
+        long long part = (lane <= stop) ? static_cast<long long>(st & VALUE) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        prefix += part;
+        if (has_prefix) break;
+        look -= 64;
+      }
+    }
+    if (lane == 0) {
+      ag_scan_state_store(state + AG_SCAN_HEADER + tile, FLAG_PREFIX | static_cast<unsigned long long>(prefix + block_total));
+      s_prefix = prefix;
+    }
+  }
+  __syncthreads();
+  long long run = s_prefix + thread_excl;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    if (first + i < n) out[first + i] = static_cast<T>(run);
+    run += v[i];
+  }
+  if (tile == ntiles - 1 && tid == 255) out[n] = static_cast<T>(s_prefix + block_total);
+  if (want_max && tid == 0) {
+    long long m = s_max[0];
+    for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
+    atomicMax(state + 2, static_cast<unsigned long long>(m));
+    __threadfence();
+    const unsigned long long done = atomicAdd(state + 1, 1ull);
+    if (done == static_cast<unsigned long long>(ntiles - 1)) out[n + 1] = static_cast<T>(atomicMax(state + 2, 0ull));
+  }
+}
+
+// d_state: ag_chained_scan_state_words_*(n) zeroed 64-bit words (see above)
+int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long long* d_state, hipStream_t stream) {
+  if (n <= 0) return AG_OK;
+  AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int>, dim3(static_cast<unsigned>(ag_scan_tiles<int>(n))),
+            dim3(256), stream, d_in, d_out, n, d_state, 0);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+int ag_chained_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n, unsigned long long* d_state, int want_max,
+                        hipStream_t stream) {
+  if (n <= 0) return AG_OK;
+  AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int64_t>,
+            dim3(static_cast<unsigned>(ag_scan_tiles<int64_t>(n))), dim3(256), stream, d_in, d_out, n, d_state, want_max);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
 size_t ag_scan_i64_temp_bytes(int64_t n) {
   size_t bytes = 0;
   int64_t* p = nullptr;

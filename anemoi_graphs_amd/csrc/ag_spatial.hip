@@ -26,12 +26,16 @@
 // ---------------------------------------------------------------------------------------------
 // grid construction
 // ---------------------------------------------------------------------------------------------
-// Block 0 computes the band tables; every block clears its share of the cell counters.
+// Block 0 computes the band tables; every block clears its share of the cell counters and of the
+// state words of the scan that turns the counters into cell starts.
 __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat, int mult, int* __restrict__ ncols,
                                                              int* __restrict__ off, double* __restrict__ win,
-                                                             int* __restrict__ cell_count, int64_t ncount) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < ncount; i += int64_t(gridDim.x) * blockDim.x)
-    cell_count[i] = 0;
+                                                             int* __restrict__ cell_count, int64_t ncount,
+                                                             unsigned long long* __restrict__ scan_state,
+                                                             int64_t nstate) {
+  const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = gtid; i < ncount; i += gsize) cell_count[i] = 0;
+  for (int64_t i = gtid; i < nstate; i += gsize) scan_state[i] = 0ull;  // state of the scan of the counters
   if (blockIdx.x != 0) return;
   __shared__ int partial[1024];
   const int tid = threadIdx.x;
@@ -141,8 +145,8 @@ struct AgBinCarve {
   int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids;
   double* win;
   float4* pts;
-  void* scan_temp;
-  size_t scan_temp_bytes;
+  unsigned long long* scan_state;
+  int64_t scan_words;
 };
 
 static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool want_pts, AgBinCarve* c) {
@@ -154,8 +158,8 @@ static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool
   c->cell_of = ws.take<int>(n);
   c->slot_of = ws.take<int>(n);
   c->ids = ws.take<int>(n);
-  c->scan_temp_bytes = ag_scan_i32_temp_bytes(cells);
-  c->scan_temp = ws.take<char>(c->scan_temp_bytes);
+  c->scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i32(cells));
+  c->scan_state = ws.take<unsigned long long>(c->scan_words);
   c->pts = want_pts ? ws.take<float4>(n) : nullptr;
 }
 
@@ -182,14 +186,14 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   ag_bin_describe(c, n, nb, mult, out);
   const int64_t ncells_ub = out->ncells_ub;
   AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(ncells_ub + 1, 4096, 256)), dim3(1024), stream,
-            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1);
+            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1, c.scan_state, c.scan_words);
   AG_LAUNCH_CHECK();
   int rc = AG_OK;
   const int blocks = ag_blocks(n, 256, 16384);
   AG_KERNEL("ag_bin_count_kernel", ag_bin_count_kernel, dim3(blocks), dim3(256), stream, out->grid,
             reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start);
   AG_LAUNCH_CHECK();
-  rc = ag_exclusive_scan_i32(c.scan_temp, c.scan_temp_bytes, c.cell_start, c.cell_start, ncells_ub + 1, stream);
+  rc = ag_chained_scan_i32(c.cell_start, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> [ncells_ub]
   if (rc) return rc;
   AG_KERNEL("ag_bin_scatter_kernel", ag_bin_scatter_kernel, dim3(blocks), dim3(256), stream,
             reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start, c.pts, c.ids);
@@ -928,6 +932,8 @@ struct AgRadiusArgs {
   int32_t* stash;    // [nt * stash_cap] sorted rows of at most stash_cap entries, written by the count pass
   int stash_cap;
   AgRadiusDesc* desc;  // [nt]
+  unsigned long long* scan_state;  // state words of the scan of the counts, cleared by the window kernel
+  int64_t scan_words;
 };
 
 // rows the count pass can keep: as long as possible within a fixed budget of entries
@@ -940,6 +946,9 @@ static int ag_radius_stash_cap(int64_t nt) {
 // The float64 window arithmetic is paid once per target here, not once per wave instruction in
 // the search.
 __global__ __launch_bounds__(256) void ag_radius_window_kernel(AgRadiusArgs a) {
+  if (a.scan_state != nullptr)  // (count pass only) the scan that follows the count kernel starts from zeroed state
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < a.scan_words; i += int64_t(gridDim.x) * blockDim.x)
+      a.scan_state[i] = 0ull;
   for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < a.nt; t += int64_t(gridDim.x) * blockDim.x) {
     const float2 tpf = a.tgt[t];
     const float3 tu = ag_unit_vec(tpf.x, tpf.y);
@@ -1156,38 +1165,16 @@ __global__ __launch_bounds__(256) void ag_radius_long_finish_kernel(AgRadiusArgs
   }
 }
 
-// largest row of the count pass (before the counts are turned into offsets)
-__global__ __launch_bounds__(256) void ag_radius_max_row_kernel(const int64_t* __restrict__ counts, int64_t nt,
-                                                                unsigned long long* __restrict__ out) {
-  __shared__ long long sh[4];
-  long long m = 0;
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < nt; i += int64_t(gridDim.x) * blockDim.x)
-    m = max(m, static_cast<long long>(counts[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-  if (ag_lane() == 0) sh[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
-    atomicMax(out, static_cast<unsigned long long>(m));
-  }
-}
-
-__global__ void ag_radius_store_max_kernel(const unsigned long long* __restrict__ m, int64_t* __restrict__ out) {
-  *out = static_cast<int64_t>(*m);
-}
-
 struct AgRadiusWs {
   AgBinned src;
-  void* scan_temp;
-  size_t scan_temp_bytes;
+  unsigned long long* scan_state;
+  int64_t scan_words;
   int32_t* stash;
   int stash_cap;
   AgRadiusDesc* desc;
   uint32_t *seg_begin, *seg_end;  // [nt] segments of the rows longer than the stash
   void* seg_temp;
   size_t seg_temp_bytes;
-  unsigned long long* max_row;
 };
 
 // cell size for a radius query: the query radius itself, but never so small that the grid has
@@ -1217,8 +1204,8 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
     ag_bin_carve(c, ns, nb_reserve, 1, true, &bc);
     ag_bin_describe(bc, ns, nb, 1, &w->src);
   }
-  const size_t stb = ag_scan_i64_temp_bytes(nt);
-  void* st = c.take<char>(stb);
+  const int64_t scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i64(nt));
+  unsigned long long* scan_state = c.take<unsigned long long>(scan_words);
   const int cap = ag_radius_stash_cap(nt);
   int32_t* stash = c.take<int32_t>(nt * cap + 4);
   AgRadiusDesc* desc = c.take<AgRadiusDesc>(nt);
@@ -1226,16 +1213,14 @@ static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_
   uint32_t* seg_end = c.take<uint32_t>(nt);
   const size_t seg_temp_bytes = ag_segmented_sort_i32_temp_bytes(nt);
   void* seg_temp = c.take<char>(seg_temp_bytes);
-  unsigned long long* max_row = c.take<unsigned long long>(2);
   if (w) {
     w->seg_begin = seg_begin;
     w->seg_end = seg_end;
     w->seg_temp = seg_temp;
     w->seg_temp_bytes = seg_temp_bytes;
-    w->max_row = max_row;
     w->desc = desc;
-    w->scan_temp = st;
-    w->scan_temp_bytes = stb;
+    w->scan_state = scan_state;
+    w->scan_words = scan_words;
     w->stash = stash;
     w->stash_cap = cap;
   }
@@ -1260,6 +1245,8 @@ static int ag_radius_args(const float* d_src, const float* d_tgt, int64_t nt, do
   a->stash = w.stash;
   a->stash_cap = w.stash_cap;
   a->desc = w.desc;
+  a->scan_state = nullptr;
+  a->scan_words = 0;
   a->radius = radius < AG_PI ? radius : AG_PI;
   const double s = sin(0.5 * radius);
   a->rthr = s * s;
@@ -1293,25 +1280,17 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
   a.offsets = d_offsets;
   a.out_src = nullptr;
   a.out_tgt = nullptr;
+  a.scan_state = w.scan_state;
+  a.scan_words = w.scan_words;
   if (nt > 0) {
     AG_KERNEL("ag_radius_window_kernel", ag_radius_window_kernel, dim3(ag_blocks(nt, 256, 16384)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
     AG_KERNEL("ag_radius_count_kernel", ag_radius_count_kernel, dim3(ag_blocks(nt, 4, 16384)), dim3(256), s, a);
     AG_LAUNCH_CHECK();
   }
-  // offsets[nt + 1] = the longest row (taken from the counts, before they become offsets)
-  int rcz = ag_zero_i32(reinterpret_cast<int*>(w.max_row), 2, s);
-  if (rcz) return rcz;
-  if (nt > 0) {
-    AG_KERNEL("ag_radius_max_row_kernel", ag_radius_max_row_kernel, dim3(ag_blocks(nt, 256 * 8, 256)), dim3(256), s,
-              d_offsets, nt, w.max_row);
-    AG_LAUNCH_CHECK();
-  }
-  int rc2 = ag_exclusive_scan_i64(w.scan_temp, w.scan_temp_bytes, d_offsets, d_offsets, nt, s);
-  if (rc2) return rc2;
-  AG_KERNEL("ag_radius_store_max_kernel", ag_radius_store_max_kernel, dim3(1), dim3(1), s, w.max_row, d_offsets + nt + 1);
-  AG_LAUNCH_CHECK();
-  return AG_OK;
+  // counts -> exclusive offsets, offsets[nt] = E, offsets[nt + 1] = the longest row, in one launch
+  if (nt == 0) return ag_zero_i32(reinterpret_cast<int*>(d_offsets), 4, s);
+  return ag_chained_scan_i64(d_offsets, d_offsets, nt, w.scan_state, 1, s);
 }
 
 extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
