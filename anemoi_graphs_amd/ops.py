@@ -285,7 +285,13 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
                                     _ptr(count), _ptr(ws), ws.numel(), _stream(dev)),
             "ag_multiscale_count",
         )
-        num_edges = int(count.item())
+        if act is None and x_hops == 1 and len(set(int(v) for v in levels)) == len(levels):
+            # The complete icosphere needs no answer from the device: level l has 30 * 4^l undirected
+            # edges, each listed in both directions, and edges of different levels never coincide (a
+            # level's edge is split by a midpoint on the next), so the host does not wait here.
+            num_edges = sum(60 * 4 ** int(v) for v in levels)
+        else:
+            num_edges = int(count.item())
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
         if num_edges:
             _lib.check(
