@@ -191,12 +191,46 @@ __global__ void ag_ico_emit_kernel(int64_t V, int64_t Eu, const int* __restrict_
                                    int* __restrict__ error_flag) {
   ag_ico_emit_range(AG_GRID_I0, AG_GRID_STEP, V, Eu, first, nb, uniq, xyz, write_midpoints, error_flag);
 }
-__global__ void ag_ico_subdivide_kernel(const int32_t* __restrict__ fin, int64_t F, const int* __restrict__ first,
-                                        const int32_t* __restrict__ nb, int V, int32_t* __restrict__ fout) {
-  ag_ico_subdivide_range(AG_GRID_I0, AG_GRID_STEP, fin, F, first, nb, V, fout);
-}
-__global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V, int* __restrict__ cnt) {
-  ag_ico_project_range(AG_GRID_I0, AG_GRID_STEP, xyz, V, cnt);
+// Everything that follows the unique edges of a level, in one launch (the parts are independent of
+// each other): the four children of every face; all V + Eu vertices pushed to the unit sphere; the
+// slot counters (in the OTHER buffer than the one this level's offsets live in, which the face part
+// is still reading) and the scan state cleared for the next level; and, for the last level, its
+// unique edges with no further sort -- every parent edge (a, b) with midpoint m gives (a, m) and
+// (b, m), every parent face the three sides of its central child.
+__global__ void ag_ico_refine_kernel(const int32_t* __restrict__ fin, int64_t F, const int* __restrict__ first,
+                                     const int32_t* __restrict__ nb, int64_t V, int64_t Eu, int32_t* __restrict__ fout,
+                                     double* __restrict__ xyz, int* __restrict__ next_cnt,
+                                     unsigned long long* __restrict__ scan_state, int64_t scan_words,
+                                     const uint64_t* __restrict__ parent_edges, uint64_t* __restrict__ final_edges) {
+  const int64_t i0 = AG_GRID_I0, step = AG_GRID_STEP;
+  for (int64_t f = i0; f < F; f += step) {
+    const int a = fin[3 * f], b = fin[3 * f + 1], c = fin[3 * f + 2];
+    const int m0 = static_cast<int>(V) + ag_edge_index(first, nb, a, b);
+    const int m1 = static_cast<int>(V) + ag_edge_index(first, nb, b, c);
+    const int m2 = static_cast<int>(V) + ag_edge_index(first, nb, c, a);
+    int32_t* o = fout + 12 * f;
+    o[0] = a;  o[1] = m0; o[2] = m2;
+    o[3] = m0; o[4] = b;  o[5] = m1;
+    o[6] = m2; o[7] = m1; o[8] = c;
+    o[9] = m0; o[10] = m1; o[11] = m2;
+    if (final_edges != nullptr) {
+      uint64_t* e = final_edges + 2 * Eu + 3 * f;
+      e[0] = ag_edge_key(m0, m1);
+      e[1] = ag_edge_key(m1, m2);
+      e[2] = ag_edge_key(m2, m0);
+    }
+  }
+  if (final_edges != nullptr) {
+    for (int64_t i = i0; i < Eu; i += step) {
+      const uint64_t k = parent_edges[i];
+      const int a = static_cast<int>(static_cast<uint32_t>(k)), b = static_cast<int>(static_cast<uint32_t>(k >> 32));
+      const int m = static_cast<int>(V + i);
+      final_edges[2 * i] = ag_edge_key(a, m);
+      final_edges[2 * i + 1] = ag_edge_key(b, m);
+    }
+  }
+  ag_ico_project_range(i0, step, xyz, V + Eu, next_cnt);
+  for (int64_t i = i0; i < scan_words; i += step) scan_state[i] = 0ull;
 }
 
 // The first levels are too small to fill even one CU: a launch per step costs more than the step.
@@ -210,6 +244,7 @@ __global__ void ag_ico_project_kernel(double* __restrict__ xyz, int64_t V, int* 
 __global__ __launch_bounds__(1024) void ag_ico_small_levels_kernel(int levels, double* xyz, int32_t* faces_a,
                                                                    int32_t* faces_b, uint64_t* level_edges,
                                                                    uint64_t* uniq_scratch, int* g_first,
+                                                                   unsigned long long* scan_state, int scan_words,
                                                                    int* error_flag) {
   __shared__ int s_first[AG_ICO_SMALL_V + 2];
   __shared__ int32_t s_nb[AG_MAX_DEG * AG_ICO_SMALL_V];
@@ -283,9 +318,10 @@ __global__ __launch_bounds__(1024) void ag_ico_small_levels_kernel(int levels, d
     cur = nxt;
     nxt = t;
   }
-  // slot counters of the next (grid-wide) level
+  // slot counters and scan state of the next (grid-wide) level
   const int64_t Vn = (10ll << (2 * levels)) + 2;
   for (int64_t i = tid; i <= Vn; i += 1024) g_first[i] = 0;
+  for (int i = tid; i < scan_words; i += 1024) scan_state[i] = 0ull;
 }
 
 // descending order of a float as ascending order of an unsigned key
@@ -296,32 +332,35 @@ __device__ __forceinline__ uint32_t ag_desc_key(float v) {
   return ~u;                                        // descending
 }
 
-// generate/transforms.py:50-52
-__global__ void ag_ico_latlon_kernel(const double* __restrict__ xyz, int64_t V, float2* __restrict__ latlon) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
-    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const double lat = asin(z / (x * x + y * y + z * z));
-    const double lon = atan2(y, x);
-    latlon[i] = make_float2(static_cast<float>(lat), static_cast<float>(lon));
-  }
-}
+// Node order (generate/utils.py:15-33): latitude descending, ties longitude descending, ties node id
+// descending -- one stable sort of key = (descending-latitude key << 32) | descending-longitude key,
+// fed in descending id order.
 
-// Node-order sort input (generate/utils.py:15-33): position p holds node id = n - 1 - p
-// (descending ids, so that the stable sort breaks ties towards the larger id) with
-// key = (descending-latitude key << 32) | descending-longitude key
-__global__ void ag_order_keys_kernel(const float2* __restrict__ latlon, int64_t n, uint64_t* __restrict__ keys,
-                                     int32_t* __restrict__ ids) {
+// sort input: position p holds node id = n - 1 - p with its key; for the icosphere the coordinates
+// themselves are produced here too (generate/transforms.py:50-52)
+__global__ void ag_order_keys_kernel(const double* __restrict__ xyz, float2* __restrict__ latlon, int64_t n,
+                                     uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    const float2 p = latlon[i];
+    float2 p;
+    if (xyz != nullptr) {
+      const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+      const double lat = asin(z / (x * x + y * y + z * z));
+      const double lon = atan2(y, x);
+      p = make_float2(static_cast<float>(lat), static_cast<float>(lon));
+      latlon[i] = p;
+    } else {
+      p = latlon[i];
+    }
     const int64_t pos = n - 1 - i;
     keys[pos] = (static_cast<uint64_t>(ag_desc_key(p.x)) << 32) | ag_desc_key(p.y);
     ids[pos] = static_cast<int32_t>(i);
   }
 }
 
-__global__ void ag_ico_finish_order_kernel(const int32_t* __restrict__ order, const float2* __restrict__ latlon, int64_t V,
-                                           float2* __restrict__ out_latlon, int32_t* __restrict__ rank) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < V; i += int64_t(gridDim.x) * blockDim.x) {
+// the inverse permutation and the ordered coordinates
+__global__ void ag_order_finish_kernel(const int32_t* __restrict__ order, const float2* __restrict__ latlon, int64_t n,
+                                       float2* __restrict__ out_latlon, int32_t* __restrict__ rank) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     const int32_t id = order[i];
     rank[id] = static_cast<int32_t>(i);
     out_latlon[i] = latlon[id];
@@ -333,9 +372,10 @@ __global__ void ag_ico_finish_order_kernel(const int32_t* __restrict__ order, co
 // ---------------------------------------------------------------------------------------------
 struct AgTopoWs {
   int* first;          // [V_R + 2] slot counters, then first-edge offsets of every vertex
+  int* first_alt;      // [V_R + 2] the counters of the following level (the two alternate)
   int32_t* nb;         // [6 V_R]   smaller neighbours of every vertex
-  void* scan_temp;
-  size_t scan_temp_bytes;
+  unsigned long long* scan_state;  // state words of the scan of the counters
+  int64_t scan_words;
   uint64_t* uniq;      // [E_R]     unique edges of a level when the caller does not keep them
   uint64_t* keys_a;    // [V_R]     node-order sort keys
   uint64_t* keys_b;    // [V_R]
@@ -350,9 +390,10 @@ static void ag_topo_carve(AgCarver& c, int R, AgTopoWs* w) {
   const int64_t F = ag_ico_F(R), V = ag_ico_V(R);
   AgTopoWs t;
   t.first = c.take<int>(V + 2);
+  t.first_alt = c.take<int>(V + 2);
   t.nb = c.take<int32_t>(AG_MAX_DEG * V);
-  t.scan_temp_bytes = ag_scan_i32_temp_bytes(V + 2);
-  t.scan_temp = c.take<char>(t.scan_temp_bytes);
+  t.scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i32(V + 2));
+  t.scan_state = c.take<unsigned long long>(t.scan_words);
   t.uniq = c.take<uint64_t>(ag_ico_E(R));
   t.keys_a = c.take<uint64_t>(V);
   t.keys_b = c.take<uint64_t>(V);
@@ -365,50 +406,61 @@ static void ag_topo_carve(AgCarver& c, int R, AgTopoWs* w) {
 }
 
 // unique edges of `faces` (level l) into `uniq`, in (max vertex, min vertex) order; leaves the
-// per-vertex offsets and sorted neighbour lists in the workspace for the subdivision.  The slot
-// counters w.first[0 .. V_l] must be zero on entry.
-static int ag_topo_unique_edges(const AgTopoWs& w, const int32_t* faces, int l, uint64_t* uniq, double* xyz,
+// per-vertex offsets (in `first`) and sorted neighbour lists in the workspace for the subdivision.  The
+// slot counters first[0 .. V_l] and the scan state must be zero on entry.
+static int ag_topo_unique_edges(const AgTopoWs& w, int* first, const int32_t* faces, int l, uint64_t* uniq, double* xyz,
                                 bool write_midpoints, hipStream_t s) {
   const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
   AG_KERNEL("ag_ico_lower_kernel", ag_ico_lower_kernel, dim3(ag_blocks(3 * F, 256, 8192)), dim3(256), s, faces, F,
-            w.first, w.nb, w.error_flag);
+            first, w.nb, w.error_flag);
   AG_LAUNCH_CHECK();
-  int rc = ag_exclusive_scan_i32(w.scan_temp, w.scan_temp_bytes, w.first, w.first, V + 1, s);
+  int rc = ag_chained_scan_i32(first, first, V, w.scan_state, s);  // total -> first[V]
   if (rc) return rc;
-  AG_KERNEL("ag_ico_emit_kernel", ag_ico_emit_kernel, dim3(ag_blocks(V, 256, 8192)), dim3(256), s, V, Eu, w.first, w.nb,
+  AG_KERNEL("ag_ico_emit_kernel", ag_ico_emit_kernel, dim3(ag_blocks(V, 256, 8192)), dim3(256), s, V, Eu, first, w.nb,
             uniq, xyz, write_midpoints ? 1 : 0, w.error_flag);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
 
-// node order: latitude descending, ties longitude descending, ties node id descending -- one
-// stable sort of (latitude key, longitude key) pairs presented in descending id order
-static int ag_order_nodes(const float2* latlon, int64_t n, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_a,
-                          void* sort_temp, size_t sort_temp_bytes, int32_t* d_order, hipStream_t s) {
-  AG_KERNEL("ag_order_keys_kernel", ag_order_keys_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s, latlon, n, keys_a,
-            ids_a);
+// node order of n nodes: `xyz` (nullable) are the unit vectors the coordinates are computed from first;
+// d_order receives the node ids in order, out_latlon / rank (nullable) the ordered coordinates and the
+// inverse permutation
+struct AgOrderWs {
+  uint64_t *keys_a, *keys_b;
+  int32_t* ids_a;
+  void* sort_temp;
+  size_t sort_temp_bytes;
+};
+
+static int ag_order_nodes(const double* xyz, float2* latlon, int64_t n, const AgOrderWs& w, int32_t* d_order,
+                          float2* out_latlon, int32_t* rank, hipStream_t s) {
+  const int nb = ag_blocks(n, 256, 8192);
+  AG_KERNEL("ag_order_keys_kernel", ag_order_keys_kernel, dim3(nb), dim3(256), s, xyz, latlon, n, w.keys_a, w.ids_a);
   AG_LAUNCH_CHECK();
-  return ag_sort_pairs_u64_i32(sort_temp, sort_temp_bytes, keys_a, keys_b, ids_a, d_order, n, s);
+  int rc = ag_sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.ids_a, d_order, n, s);
+  if (rc) return rc;
+  if (rank != nullptr) {
+    AG_KERNEL("ag_order_finish_kernel", ag_order_finish_kernel, dim3(nb), dim3(256), s, d_order, latlon, n, out_latlon,
+              rank);
+    AG_LAUNCH_CHECK();
+  }
+  return AG_OK;
 }
 
-static void ag_node_order_carve(AgCarver& c, int64_t n, uint64_t** ka, uint64_t** kb, int32_t** ids, void** temp,
-                                size_t* temp_bytes) {
-  uint64_t* a = c.take<uint64_t>(n);
-  uint64_t* b = c.take<uint64_t>(n);
-  int32_t* i = c.take<int32_t>(n);
-  const size_t tb = ag_sort_pairs_u64_i32_temp_bytes(n);
-  void* t = c.take<char>(tb);
-  if (ka) *ka = a;
-  if (kb) *kb = b;
-  if (ids) *ids = i;
-  if (temp) *temp = t;
-  if (temp_bytes) *temp_bytes = tb;
+static void ag_node_order_carve(AgCarver& c, int64_t n, AgOrderWs* w) {
+  AgOrderWs t;
+  t.keys_a = c.take<uint64_t>(n);
+  t.keys_b = c.take<uint64_t>(n);
+  t.ids_a = c.take<int32_t>(n);
+  t.sort_temp_bytes = ag_sort_pairs_u64_i32_temp_bytes(n);
+  t.sort_temp = c.take<char>(t.sort_temp_bytes);
+  if (w) *w = t;
 }
 
 extern "C" size_t ag_node_order_workspace_bytes(int64_t n) {
   if (n < 1) return 0;
   AgCarver c(nullptr);
-  ag_node_order_carve(c, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+  ag_node_order_carve(c, n, nullptr);
   return c.total();
 }
 
@@ -419,13 +471,10 @@ extern "C" int ag_node_order(const float* d_latlon, int64_t n, int32_t* d_order,
   AG_REQUIRE(d_latlon && d_order && d_ws, "ag_node_order: null pointer");
   if (ws_bytes < ag_node_order_workspace_bytes(n)) return ag_fail(AG_ERR_WORKSPACE, "ag_node_order: workspace too small");
   AgCarver c(d_ws);
-  uint64_t *ka, *kb;
-  int32_t* ids;
-  void* temp;
-  size_t temp_bytes;
-  ag_node_order_carve(c, n, &ka, &kb, &ids, &temp, &temp_bytes);
-  return ag_order_nodes(reinterpret_cast<const float2*>(d_latlon), n, ka, kb, ids, temp, temp_bytes, d_order,
-                        static_cast<hipStream_t>(stream));
+  AgOrderWs w;
+  ag_node_order_carve(c, n, &w);
+  return ag_order_nodes(nullptr, const_cast<float2*>(reinterpret_cast<const float2*>(d_latlon)), n, w, d_order, nullptr,
+                        nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ag_icosphere_sizes(int R, int64_t* V, int64_t* F, int64_t* E_all) {
@@ -462,7 +511,7 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   // levels 0 .. small-1 in one block; the face ping-pong continues from where it ends
   const int small = R < AG_ICO_SMALL_LEVELS ? R : AG_ICO_SMALL_LEVELS;
   AG_KERNEL("ag_ico_small_levels_kernel", ag_ico_small_levels_kernel, dim3(1), dim3(1024), s, small, d_xyz, cur, nxt,
-            d_level_edges, w.uniq, w.first, w.error_flag);
+            d_level_edges, w.uniq, w.first, w.scan_state, static_cast<int>(w.scan_words), w.error_flag);
   AG_LAUNCH_CHECK();
   if (small % 2 == 1) {
     int32_t* t = cur;
@@ -477,41 +526,39 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
               d_level_edges + ag_ico_edge_offset(l), Eu, V, cur, F, d_level_edges + ag_ico_edge_offset(R));
     AG_LAUNCH_CHECK();
   }
+  int* first = w.first;      // zeroed by the small-levels kernel
+  int* first_next = w.first_alt;
   for (int l = small; l < R; ++l) {
     const int64_t F = ag_ico_F(l), Eu = ag_ico_E(l), V = ag_ico_V(l);
     // the unique edges of level l go straight into the per-level edge array when the caller wants it
     uint64_t* uniq = d_level_edges ? d_level_edges + ag_ico_edge_offset(l) : w.uniq;
-    rc = ag_topo_unique_edges(w, cur, l, uniq, d_xyz, true, s);
+    rc = ag_topo_unique_edges(w, first, cur, l, uniq, d_xyz, true, s);
     if (rc) return rc;
-    AG_KERNEL("ag_ico_subdivide_kernel", ag_ico_subdivide_kernel, dim3(ag_blocks(F, 256, 8192)), dim3(256), s, cur, F,
-              w.first, w.nb, static_cast<int>(V), nxt);
+    const bool last = d_level_edges && l == R - 1;
+    AG_KERNEL("ag_ico_refine_kernel", ag_ico_refine_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), s, cur, F, first,
+              w.nb, V, Eu, nxt, d_xyz, first_next, w.scan_state, w.scan_words, uniq,
+              last ? d_level_edges + ag_ico_edge_offset(R) : nullptr);
     AG_LAUNCH_CHECK();
-    AG_KERNEL("ag_ico_project_kernel", ag_ico_project_kernel, dim3(ag_blocks(V + Eu, 256, 8192)), dim3(256), s, d_xyz,
-              V + Eu, w.first);
-    AG_LAUNCH_CHECK();
-    if (d_level_edges && l == R - 1) {
-      AG_KERNEL("ag_ico_final_edges_kernel", ag_ico_final_edges_kernel, dim3(ag_blocks(Eu + F, 256, 8192)), dim3(256),
-                s, uniq, Eu, V, nxt, F, d_level_edges + ag_ico_edge_offset(R));
-      AG_LAUNCH_CHECK();
-    }
     int32_t* t = cur;
     cur = nxt;
     nxt = t;
+    int* tf = first;
+    first = first_next;
+    first_next = tf;
   }
   if (d_level_edges && R == 0) {
-    rc = ag_topo_unique_edges(w, cur, 0, d_level_edges, d_xyz, false, s);
+    rc = ag_topo_unique_edges(w, first, cur, 0, d_level_edges, d_xyz, false, s);
     if (rc) return rc;
   }
   const int64_t V = ag_ico_V(R);
   const int vb = ag_blocks(V, 256, 8192);
-  AG_KERNEL("ag_ico_latlon_kernel", ag_ico_latlon_kernel, dim3(vb), dim3(256), s, d_xyz, V, latlon);
-  AG_LAUNCH_CHECK();
-  rc = ag_order_nodes(latlon, V, w.keys_a, w.keys_b, w.ids_a, w.sort_temp, w.sort_temp_bytes, d_order, s);
-  if (rc) return rc;
-  AG_KERNEL("ag_ico_finish_order_kernel", ag_ico_finish_order_kernel, dim3(vb), dim3(256), s, d_order, latlon, V,
-            reinterpret_cast<float2*>(d_latlon), d_rank);
-  AG_LAUNCH_CHECK();
-  return AG_OK;
+  AgOrderWs ow;
+  ow.keys_a = w.keys_a;
+  ow.keys_b = w.keys_b;
+  ow.ids_a = w.ids_a;
+  ow.sort_temp = w.sort_temp;
+  ow.sort_temp_bytes = w.sort_temp_bytes;
+  return ag_order_nodes(d_xyz, latlon, V, ow, d_order, reinterpret_cast<float2*>(d_latlon), d_rank, s);
 }
 
 // ---------------------------------------------------------------------------------------------
