@@ -377,7 +377,8 @@ int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream);
 // single-launch exclusive scans; d_state = *_state_words(n) 64-bit words the caller has zeroed
 size_t ag_chained_scan_state_words_i32(int64_t n);
 size_t ag_chained_scan_state_words_i64(int64_t n);
-int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long long* d_state, hipStream_t stream);
+int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long long* d_state, hipStream_t stream,
+                        long long* d_total = nullptr);
 int ag_chained_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n, unsigned long long* d_state, int want_max,
                         hipStream_t stream);
 size_t ag_scan_i64_temp_bytes(int64_t n);

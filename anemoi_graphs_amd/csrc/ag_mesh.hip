@@ -619,10 +619,6 @@ __global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ level_edges
   }
 }
 
-__global__ void ag_ms_total_i32_kernel(const int* __restrict__ offsets, int64_t n, int64_t* __restrict__ out) {
-  *out = offsets[n];
-}
-
 __global__ void ag_ms_scatter_kernel(const uint64_t* __restrict__ pairs, const int* __restrict__ slot, int64_t n, int B,
                                      const int* __restrict__ row_start, int32_t* __restrict__ out_src,
                                      int32_t* __restrict__ out_tgt) {
@@ -746,6 +742,8 @@ struct AgMsWs {
   int64_t* offsets;   // [total slots + 1]
   int* slot;          // [total slots]  position of a pair inside its target's row   (x_hops == 1)
   int* row_start;     // [V_R + 1]      row counters, then row offsets               (x_hops == 1)
+  int64_t row_clear;  // ints to clear from row_start on: the counters and the scan state behind them
+  unsigned long long* row_scan_state;
   int32_t* unsorted;  // [total slots]  sources grouped by target, unsorted inside a row (x_hops == 1)
   void* temp;
   size_t temp_bytes;
@@ -771,7 +769,12 @@ static int ag_ms_carve(AgCarver& c, int R, const int32_t* levels, int nlevels, i
   m.pairs_b = x_hops > 1 ? c.take<uint64_t>(slots) : nullptr;
   m.offsets = x_hops > 1 ? c.take<int64_t>(slots + 1) : nullptr;
   m.slot = x_hops == 1 ? c.take<int>(slots) : nullptr;
-  m.row_start = x_hops == 1 ? c.take<int>(ag_ico_V(R) + 2) : nullptr;
+  // row counters and, right behind them, the state words of their scan: one clearing launch covers both
+  const int64_t row_ints = ag_ico_V(R) + 2 + (ag_ico_V(R) & 1);  // even, so that the state is 8-byte aligned
+  const int64_t scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i32(ag_ico_V(R) + 2));
+  m.row_start = x_hops == 1 ? c.take<int>(row_ints + 2 * scan_words) : nullptr;
+  m.row_clear = row_ints + 2 * scan_words;
+  m.row_scan_state = x_hops == 1 ? reinterpret_cast<unsigned long long*>(m.row_start + row_ints) : nullptr;
   m.unsorted = x_hops == 1 ? c.take<int32_t>(slots) : nullptr;
   size_t t1 = ag_sort_u64_temp_bytes(slots), t2 = ag_scan_i64_temp_bytes(slots);
   if (x_hops == 1) {
@@ -838,16 +841,14 @@ extern "C" int ag_multiscale_count(int R, const int32_t* levels, int nlevels, in
       lv.end[i] = run;
     }
     const int64_t V = ag_ico_V(R);
-    rc = ag_zero_i32(m.row_start, V + 1, s);
+    rc = ag_zero_i32(m.row_start, m.row_clear, s);
     if (rc) return rc;
     AG_KERNEL("ag_ms_edge_pairs_kernel", ag_ms_edge_pairs_kernel, dim3(ag_blocks(run, 256, 8192)), dim3(256), s,
               d_level_edges, lv, d_active, d_rank, B, m.pairs_a, m.slot, m.row_start);
     AG_LAUNCH_CHECK();
-    rc = ag_exclusive_scan_i32(m.temp, m.temp_bytes, m.row_start, m.row_start, V + 1, s);
-    if (rc) return rc;
-    AG_KERNEL("ag_ms_total_i32_kernel", ag_ms_total_i32_kernel, dim3(1), dim3(1), s, m.row_start, V, d_num_edges);
-    AG_LAUNCH_CHECK();
-    return AG_OK;
+    // row offsets; the total lands in row_start[V] and, as int64, in *d_num_edges
+    return ag_chained_scan_i32(m.row_start, m.row_start, V, m.row_scan_state, s,
+                               reinterpret_cast<long long*>(d_num_edges));
   } else {
     for (int i = 0; i < nlevels; ++i) {
       const int l = levels[i];

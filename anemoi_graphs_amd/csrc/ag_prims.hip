@@ -225,7 +225,8 @@ int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream) {
 // The state words -- AG_SCAN_HEADER + number of tiles -- must be ZERO when the kernel starts; the
 // callers have a kernel upstream that clears them along with its own counters, which is what makes
 // this one launch instead of an initialisation launch plus a scan launch.
-// out[n] receives the total; with want_max, out[n + 1] the largest input value.  in == out is allowed.
+// out[n] receives the total (and *total_out, if given); with want_max, out[n + 1] the largest input
+// value.  in == out is allowed.
 // ---------------------------------------------------------------------------------------------
 #define AG_SCAN_HEADER 8  // [0] ticket, [1] tiles finished, [2] running maximum
 
@@ -262,7 +263,8 @@ __device__ __forceinline__ void ag_scan_state_store(unsigned long long* p, unsig
 
 template <class T>
 __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* out, int64_t n,
-                                                              unsigned long long* __restrict__ state, int want_max) {
+                                                              unsigned long long* __restrict__ state, int want_max,
+                                                              long long* __restrict__ total_out) {
   constexpr int ITEMS = AgScanTile<T>::ITEMS;
   constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_PREFIX = 2ull << 62, VALUE = (1ull << 62) - 1ull;
   __shared__ unsigned s_tile;
@@ -344,7 +346,10 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
     if (first + i < n) out[first + i] = static_cast<T>(run);
     run += v[i];
   }
-  if (tile == ntiles - 1 && tid == 255) out[n] = static_cast<T>(s_prefix + block_total);
+  if (tile == ntiles - 1 && tid == 255) {
+    out[n] = static_cast<T>(s_prefix + block_total);
+    if (total_out != nullptr) *total_out = s_prefix + block_total;
+  }
   if (want_max && tid == 0) {
     long long m = s_max[0];
     for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
@@ -356,10 +361,11 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
 }
 
 // d_state: ag_chained_scan_state_words_*(n) zeroed 64-bit words (see above)
-int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long long* d_state, hipStream_t stream) {
+int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long long* d_state, hipStream_t stream,
+                        long long* d_total) {
   if (n <= 0) return AG_OK;
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int>, dim3(static_cast<unsigned>(ag_scan_tiles<int>(n))),
-            dim3(256), stream, d_in, d_out, n, d_state, 0);
+            dim3(256), stream, d_in, d_out, n, d_state, 0, d_total);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -368,7 +374,8 @@ int ag_chained_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n, unsigned
                         hipStream_t stream) {
   if (n <= 0) return AG_OK;
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int64_t>,
-            dim3(static_cast<unsigned>(ag_scan_tiles<int64_t>(n))), dim3(256), stream, d_in, d_out, n, d_state, want_max);
+            dim3(static_cast<unsigned>(ag_scan_tiles<int64_t>(n))), dim3(256), stream, d_in, d_out, n, d_state, want_max,
+            static_cast<long long*>(nullptr));
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -310,6 +310,12 @@ struct __attribute__((aligned(64))) AgWindow {
 // one thread per target cell: the runs of sources that cover the cell (stage 1 then starts with
 // two independent loads instead of a chain of dependent table look-ups per wave)
 __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the stages that follow
+    a.queue_count[0] = 0;  // stage-2 queue
+    a.queue_count[1] = 0;  // float64 re-rank queue
+    if (a.max_bits) *a.max_bits = 0ull;
+    if (a.stats) a.stats[0] = a.stats[1] = a.stats[2] = a.stats[3] = 0;
+  }
   const int ncells = a.tgrid.off[a.tgrid.nb];
   for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += gridDim.x * blockDim.x) {
     if (a.tstart[cell] >= a.tstart[cell + 1]) continue;
@@ -694,17 +700,6 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
   }
 }
 
-__global__ void ag_knn_init_kernel(int* queue_count, unsigned long long* max_bits, long long* stats) {
-  if (threadIdx.x == 0) {
-    queue_count[0] = 0;  // stage-2 queue
-    queue_count[1] = 0;  // float64 re-rank queue
-    if (max_bits) *max_bits = 0ull;
-    if (stats) {
-      stats[0] = stats[1] = stats[2] = stats[3] = 0;
-    }
-  }
-}
-
 __global__ void ag_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
   const double r = __longlong_as_double(static_cast<long long>(*max_bits));
   *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
@@ -807,10 +802,6 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   AgKnnWs w;
   int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w);
   if (rc) return rc;
-  AG_KERNEL("ag_knn_init_kernel", ag_knn_init_kernel, dim3(1), dim3(64), stream, w.queue_count, w.max_bits,
-            reinterpret_cast<long long*>(d_stats));
-  AG_LAUNCH_CHECK();
-
   AgKnnArgs a;
   a.sgrid = w.src.grid;
   a.tgrid = w.tgt.grid;
