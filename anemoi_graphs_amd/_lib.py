@@ -42,6 +42,8 @@ SIGNATURES = {
     "ag_normalise": (c_int, [_P, c_int64, c_int, c_int, _P, c_size_t, _P]),
     "ag_normalise_f64": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _P]),
     "ag_voronoi_areas_knn": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P]),
+    "ag_voronoi_far_workspace_bytes": (c_size_t, [c_int64]),
+    "ag_voronoi_areas_far": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "ag_voronoi_areas_rows": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_double, _P, _P, _P]),
     "ag_sort_edges_workspace_bytes": (c_size_t, [c_int64]),
     "ag_sort_edges": (c_int, [_P, _P, c_int64, c_int, _P, c_size_t, _P]),

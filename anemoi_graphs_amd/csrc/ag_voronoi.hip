@@ -20,7 +20,21 @@
 // the two arguments of scipy's calculate_solid_angles (Van Oosterom-Strackee).
 #include "ag_common.hpp"
 
-#define AG_VOR_T 2.0  // half-width of the initial square (gnomonic units): 63 degrees
+// Half-width of the initial square in gnomonic units.  Cells are built in a square reaching 63 degrees
+// from the generator, which keeps every intermediate vertex near the size of the final cell (full
+// relative precision); only a cell that still touches that square is rebuilt in one reaching to within
+// 1e-5 rad of 90 degrees.  A cell that extends farther still (a handful of nodes on the whole sphere,
+// or the rim of a node set that leaves most of the sphere empty) cannot be represented in the chart of
+// its generator and is reported as unbounded.
+#define AG_VOR_T_NEAR 2.0
+#define AG_VOR_T_FAR 1.0e5
+
+// How much closer to the generator than its neighbour order suggests a boundary line can lie.  The
+// generators are float32 unit vectors: their norms differ by up to 8e-8, which moves the boundary line
+// of a neighbour at angular distance t by up to 8e-8 / t (the cells are those of a power diagram), and
+// the neighbour tables are ordered by the haversine distance of the float32 coordinates, not by chart
+// distance.  `d` is the distance of a line from the generator (about t / 2).
+__device__ __forceinline__ double ag_vor_slack(double d) { return 1.0e-6 + 2.0e-7 / fmax(d, 1.0e-9); }
 
 // The polygon of every lane: two buffers of MAXV vertices, lane-interleaved so that lanes working on
 // the same vertex index hit different LDS banks.
@@ -85,8 +99,7 @@ struct AgVorCell {
 };
 
 template <int MAXV>
-__device__ __forceinline__ void ag_vor_init(AgVorPoly<MAXV>& P, int lane, AgVorCell& c) {
-  const double T = AG_VOR_T;
+__device__ __forceinline__ void ag_vor_init(AgVorPoly<MAXV>& P, int lane, AgVorCell& c, double T) {
   P.u[0][0][lane] = -T;
   P.v[0][0][lane] = -T;
   P.u[0][1][lane] = T;
@@ -198,17 +211,19 @@ __device__ __forceinline__ double ag_vor_area(const AgVorPoly<MAXV>& P, int lane
 #define AG_VOR_DUPLICATE (-1.0)
 #define AG_VOR_OVERFLOW (-2.0)
 
-__device__ __forceinline__ double ag_vor_security_radius(double rho2max) {
-  const double T = AG_VOR_T;
-  if (rho2max >= T * T * (1.0 - 1.0e-9)) return __builtin_huge_val();
-  return 2.0 * atan(sqrt(rho2max)) * (1.0 + 1.0e-6) + 1.0e-6;
+__device__ __forceinline__ bool ag_vor_touches_square(double rho2max, double T) {
+  return rho2max >= T * T * (1.0 - 1.0e-9);
+}
+
+__device__ __forceinline__ double ag_vor_security_radius(double rho2max, double T) {
+  if (ag_vor_touches_square(rho2max, T)) return __builtin_huge_val();
+  const double rho = sqrt(rho2max);
+  return 2.0 * atan(rho + ag_vor_slack(rho)) * (1.0 + 1.0e-6) + 1.0e-6;
 }
 
 // Neighbours from a table: d_nbr[i*K + j] = j-th nearest node of node i (nearest first; the node
 // itself may be among them).  A farther neighbour cannot cut the polygon once the boundary line of
-// the current one passes outside every vertex; the slack covers the difference between the ordering
-// of the table (haversine of the float32 latitudes / longitudes) and the chart distances of the
-// float32 unit vectors (both within 3e-7 of the true angles).
+// the current one passes outside every vertex by more than ag_vor_slack.
 template <int MAXV>
 __global__ __launch_bounds__(64) void ag_voronoi_knn_kernel(const float2* __restrict__ x, int64_t n,
                                                             const int32_t* __restrict__ nbr, int K,
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(64) void ag_voronoi_knn_kernel(const float2* __rest
   ag_vor_xyz(x, i, &px, &py, &pz);
   const AgVorFrame f = ag_vor_frame(px, py, pz);
   AgVorCell c;
-  ag_vor_init(P, lane, c);
+  ag_vor_init(P, lane, c, AG_VOR_T_NEAR);
   bool closed = false;
   for (int j = 0; j < K && !c.overflow; ++j) {
     const int64_t q = nbr[i * K + j];
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(64) void ag_voronoi_knn_kernel(const float2* __rest
       c.duplicate = true;
       continue;
     }
-    if (dist - 1.0e-6 > sqrt(c.rho2max) * (1.0 + 1.0e-6) + 1.0e-6) {
+    if (dist - ag_vor_slack(dist) > sqrt(c.rho2max) * (1.0 + 1.0e-6)) {
       closed = true;
       break;
     }
@@ -241,7 +256,9 @@ __global__ __launch_bounds__(64) void ag_voronoi_knn_kernel(const float2* __rest
   }
   // (a polygon that outgrew this kernel's buffer is still a superset of the cell: its security radius
   // is valid, and the row kernel with its larger buffer finishes the cell)
-  double r = (closed && !c.overflow) ? 0.0 : ag_vor_security_radius(c.rho2max);
+  // (a polygon that still has a side of the initial square is not a cell yet, whatever the ordering says)
+  if (ag_vor_touches_square(c.rho2max, AG_VOR_T_NEAR)) closed = false;
+  double r = (closed && !c.overflow) ? 0.0 : ag_vor_security_radius(c.rho2max, AG_VOR_T_NEAR);
   if (c.duplicate) r = AG_VOR_DUPLICATE;
   area[i] = ag_vor_area(P, lane, c, f.norm);
   reach[i] = r;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(64) void ag_voronoi_rows_kernel(const float2* __res
   ag_vor_xyz(x, i, &px, &py, &pz);
   const AgVorFrame f = ag_vor_frame(px, py, pz);
   AgVorCell c;
-  ag_vor_init(P, lane, c);
+  c.duplicate = false;
   const int64_t e0 = offsets[t], e1 = offsets[t + 1];
   // distance range of the boundary lines of the row
   double dmin = __builtin_huge_val(), dmax = 0.0;
@@ -286,6 +303,12 @@ __global__ __launch_bounds__(64) void ag_voronoi_rows_kernel(const float2* __res
     if (dist > 0.0) dmin = fmin(dmin, dist);
     dmax = fmax(dmax, dist);
   }
+  const bool duplicate = c.duplicate;
+  double T = AG_VOR_T_NEAR;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  T = attempt == 0 ? AG_VOR_T_NEAR : AG_VOR_T_FAR;
+  ag_vor_init(P, lane, c, T);
+  c.duplicate = duplicate;
   double lo = -__builtin_huge_val(), hi = 2.0 * dmin;
   while (!c.overflow && !c.duplicate && dmin <= dmax) {
     for (int64_t e = e0; e < e1 && !c.overflow; ++e) {
@@ -295,20 +318,165 @@ __global__ __launch_bounds__(64) void ag_voronoi_rows_kernel(const float2* __res
       ag_vor_xyz(x, q, &qx, &qy, &qz);
       const double dist = ag_vor_line(f, qx, qy, qz, &c0, &a, &b);
       if (!(dist >= lo && dist < hi)) continue;
-      if (dist - 1.0e-6 > sqrt(c.rho2max) * (1.0 + 1.0e-6) + 1.0e-6) continue;
+      if (dist - ag_vor_slack(dist) > sqrt(c.rho2max) * (1.0 + 1.0e-6)) continue;
       ag_vor_clip(P, lane, c, c0, a, b);
     }
     if (hi > dmax) break;                                                    // every line was offered
-    if (hi - 1.0e-6 > sqrt(c.rho2max) * (1.0 + 1.0e-6) + 1.0e-6) break;  // no farther line reaches the polygon
+    if (hi - ag_vor_slack(hi) > sqrt(c.rho2max) * (1.0 + 1.0e-6)) break;  // no farther line reaches the polygon
     lo = hi;
     hi *= 2.0;
   }
-  double r = ag_vor_security_radius(c.rho2max);
+  if (c.overflow || c.duplicate || !ag_vor_touches_square(c.rho2max, T)) break;
+  }
+  double r = ag_vor_security_radius(c.rho2max, T);
   if (r <= radius) r = 0.0;
   if (c.overflow) r = AG_VOR_OVERFLOW;
   if (c.duplicate) r = AG_VOR_DUPLICATE;
   area[i] = ag_vor_area(P, lane, c, f.norm);
   reach[i] = r;
+}
+
+// Cells that reach 90 degrees or more away from their generator (the rim of a node set that leaves
+// part of the sphere empty, or a handful of nodes on the whole sphere) do not fit the chart of their
+// generator -- but a cell with at least two neighbours lies inside some open hemisphere, and the chart
+// may be centred anywhere in it: the half-space of q is still c0 + a u + b v >= 0, now with
+// (c0, a, b) = (c, e1, e2).(p - q) for the chart centre c.  One thread per such cell: build the part
+// of the cell visible from p, re-centre the chart on the mean direction of its vertices (a point of
+// the cell, looking towards the side that ran off the chart), rebuild, repeat while a side of the
+// initial square survives.  Every node is offered (a wide cell has no useful security radius), in
+// bands of doubling line distance as in the row kernel; the unit vectors come from a table.  The
+// area is scipy's formula on the three-dimensional vertices.
+__global__ void ag_voronoi_xyz_kernel(const float2* __restrict__ x, int64_t n, float4* __restrict__ xyz) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const float2 c = x[i];
+    const float3 p = ag_unit_vec_f32(c.x, c.y);
+    xyz[i] = make_float4(p.x, p.y, p.z, 0.0f);
+  }
+}
+
+#define AG_VOR_RECENTRE 8  // charts tried per cell
+
+template <int MAXV>
+__global__ __launch_bounds__(64) void ag_voronoi_far_kernel(const float4* __restrict__ xyz, int64_t n,
+                                                            const int32_t* __restrict__ ids, int64_t nt,
+                                                            double* __restrict__ area, double* __restrict__ reach) {
+  __shared__ AgVorPoly<MAXV> P;
+  const int lane = threadIdx.x;
+  const int64_t t = blockIdx.x * int64_t(64) + lane;
+  if (t >= nt) return;
+  const int64_t i = ids[t];
+  if (i < 0 || i >= n) return;
+  const float4 pf = xyz[i];
+  const double px = pf.x, py = pf.y, pz = pf.z;
+  AgVorFrame f = ag_vor_frame(px, py, pz);
+  const double pnorm = f.norm;
+  double cx = f.hx, cy = f.hy, cz = f.hz;  // chart centre, starts at the generator
+  AgVorCell c;
+  bool done = false, duplicate = false;
+  for (int attempt = 0; attempt < AG_VOR_RECENTRE && !done; ++attempt) {
+    f = ag_vor_frame(cx, cy, cz);
+    f.px = px;
+    f.py = py;
+    f.pz = pz;
+    double dmin = __builtin_huge_val(), dmax = 0.0;
+    for (int64_t q = 0; q < n; ++q) {
+      if (q == i) continue;
+      const float4 qf = xyz[q];
+      double c0, a, b;
+      const double dist = ag_vor_line(f, qf.x, qf.y, qf.z, &c0, &a, &b);
+      if (dist == -1.0) {
+        duplicate = true;
+        continue;
+      }
+      if (dist > 0.0) dmin = fmin(dmin, dist);
+      dmax = fmax(dmax, dist);
+    }
+    ag_vor_init(P, lane, c, AG_VOR_T_FAR);
+    double lo = -__builtin_huge_val(), hi = 2.0 * dmin;
+    while (!c.overflow && !duplicate && dmin <= dmax) {
+      for (int64_t q = 0; q < n && !c.overflow; ++q) {
+        if (q == i) continue;
+        const float4 qf = xyz[q];
+        double c0, a, b;
+        const double dist = ag_vor_line(f, qf.x, qf.y, qf.z, &c0, &a, &b);
+        if (!(dist >= lo && dist < hi)) continue;
+        if (dist - ag_vor_slack(dist) > sqrt(c.rho2max) * (1.0 + 1.0e-6)) continue;
+        ag_vor_clip(P, lane, c, c0, a, b);
+      }
+      if (hi > dmax) break;
+      if (hi - ag_vor_slack(hi) > sqrt(c.rho2max) * (1.0 + 1.0e-6)) break;
+      lo = hi;
+      hi *= 2.0;
+    }
+    if (c.overflow || duplicate) break;
+    if (!ag_vor_touches_square(c.rho2max, AG_VOR_T_FAR)) {
+      done = true;
+      break;
+    }
+    // next chart centre: mean direction of the vertices of what this chart shows of the cell
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int k = 0; k < c.m; ++k) {
+      const double u = P.u[c.cur][k][lane], v = P.v[c.cur][k][lane];
+      const double il = 1.0 / sqrt(1.0 + u * u + v * v);
+      sx += (f.hx + u * f.e1x + v * f.e2x) * il;
+      sy += (f.hy + u * f.e1y + v * f.e2y) * il;
+      sz += (f.hz + u * f.e1z + v * f.e2z) * il;
+    }
+    const double sn = sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(sn > 1.0e-9)) break;
+    cx = sx / sn;
+    cy = sy / sn;
+    cz = sz / sn;
+  }
+  double total = 0.0;
+  if (done && c.m >= 3) {
+    // scipy's calculate_solid_angles on (p, v_k, v_k+1) with the unit vertices v = (h + u e1 + v e2) / L
+    auto vertex = [&](int k, double* vx, double* vy, double* vz) {
+      const double u = P.u[c.cur][k][lane], v = P.v[c.cur][k][lane];
+      const double il = 1.0 / sqrt(1.0 + u * u + v * v);
+      *vx = (f.hx + u * f.e1x + v * f.e2x) * il;
+      *vy = (f.hy + u * f.e1y + v * f.e2y) * il;
+      *vz = (f.hz + u * f.e1z + v * f.e2z) * il;
+    };
+    double ax, ay, az;
+    vertex(c.m - 1, &ax, &ay, &az);
+    for (int k = 0; k < c.m; ++k) {
+      double bx, by, bz;
+      vertex(k, &bx, &by, &bz);
+      const double det = px * (ay * bz - az * by) + py * (az * bx - ax * bz) + pz * (ax * by - ay * bx);
+      const double den = 1.0 + (px * ax + py * ay + pz * az) + (ax * bx + ay * by + az * bz) + (bx * px + by * py + bz * pz);
+      total += fabs(2.0 * atan2(det, den));
+      ax = bx;
+      ay = by;
+      az = bz;
+    }
+  }
+  (void)pnorm;
+  double r = done ? 0.0 : __builtin_huge_val();
+  if (c.overflow) r = AG_VOR_OVERFLOW;
+  if (duplicate) r = AG_VOR_DUPLICATE;
+  area[i] = total;
+  reach[i] = r;
+}
+
+extern "C" size_t ag_voronoi_far_workspace_bytes(int64_t n) { return static_cast<size_t>(n > 0 ? n : 1) * sizeof(float4) + 256; }
+
+extern "C" int ag_voronoi_areas_far(const float* d_x, int64_t n, const int32_t* d_ids, int64_t nt, double* d_area,
+                                    double* d_reach, void* d_ws, size_t ws_bytes, void* stream) {
+  AG_REQUIRE(n >= 0 && nt >= 0, "ag_voronoi_areas_far: negative size");
+  if (n == 0 || nt == 0) return AG_OK;
+  AG_REQUIRE(d_x && d_ids && d_area && d_reach && d_ws, "ag_voronoi_areas_far: null pointer");
+  if (ws_bytes < ag_voronoi_far_workspace_bytes(n)) return ag_fail(AG_ERR_WORKSPACE, "ag_voronoi_areas_far: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AgCarver c(d_ws);
+  float4* xyz = c.take<float4>(n);
+  AG_KERNEL("ag_voronoi_xyz_kernel", ag_voronoi_xyz_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s,
+            reinterpret_cast<const float2*>(d_x), n, xyz);
+  AG_LAUNCH_CHECK();
+  AG_KERNEL("ag_voronoi_far_kernel", ag_voronoi_far_kernel<48>, dim3(ag_blocks(nt, 64)), dim3(64), s, xyz, n, d_ids, nt,
+            d_area, d_reach);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
 }
 
 extern "C" int ag_voronoi_areas_knn(const float* d_x, int64_t n, const int32_t* d_nbr, int K, double* d_area,

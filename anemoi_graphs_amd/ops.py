@@ -440,8 +440,24 @@ def voronoi_areas(x: torch.Tensor, neighbours: int = VORONOI_NEIGHBOURS, return_
                                               _ptr(area), _ptr(reach), _stream(dev)),
                     "ag_voronoi_areas_rows",
                 )
-                if radius >= math.pi:  # every node was offered: the cell is final whatever it reports
-                    reach[sel] = torch.where(reach[sel] > 0.0, torch.zeros_like(reach[sel]), reach[sel])
+                if radius >= math.pi:  # every node was offered: the cell is final ...
+                    left = reach[sel]
+                    far = sel[torch.isinf(left)]
+                    reach[sel] = torch.where(left > 0.0, torch.zeros_like(left), left)
+                    if far.numel():  # ... unless it does not fit the chart of its node: charts centred inside the cell
+                        far_ids = far.to(torch.int32).contiguous()
+                        ws = _workspace(lib.ag_voronoi_far_workspace_bytes(n), dev)
+                        _lib.check(
+                            lib.ag_voronoi_areas_far(_ptr(x), n, _ptr(far_ids), far_ids.numel(), _ptr(area), _ptr(reach),
+                                                     _ptr(ws), ws.numel(), _stream(dev)),
+                            "ag_voronoi_areas_far",
+                        )
+                        stats["far_cells"] = stats.get("far_cells", 0) + int(far.numel())
+                        if bool(torch.isinf(reach[far]).any()):
+                            raise ValueError(
+                                "voronoi_areas: a Voronoi cell spans a hemisphere (fewer than three effective "
+                                "neighbours); such cells are not supported"
+                            )
             passes += 1
             stats["row_passes"] = passes
     return (area, stats) if return_stats else area

@@ -186,6 +186,14 @@ int ag_normalise_f64(const double* d_values, int64_t n, int norm, float* d_out, 
  */
 int ag_voronoi_areas_knn(const float* d_x, int64_t n, const int32_t* d_nbr, int K, double* d_area, double* d_reach,
                          void* stream);
+/* Cells that stay unbounded (d_reach = infinity) even when every node was offered reach 90 degrees or
+ * more away from their node (the rim of a node set that leaves part of the sphere empty; a handful
+ * of nodes): ag_voronoi_areas_far rebuilds the nt cells d_ids[t] in charts centred inside the cell
+ * instead of on the node, offering every node.  d_reach[i] = 0 on success, infinity if no chart held
+ * the cell (it spans a hemisphere: fewer than three effective neighbours). */
+size_t ag_voronoi_far_workspace_bytes(int64_t n);
+int ag_voronoi_areas_far(const float* d_x, int64_t n, const int32_t* d_ids, int64_t nt, double* d_area, double* d_reach,
+                         void* d_ws, size_t ws_bytes, void* stream);
 int ag_voronoi_areas_rows(const float* d_x, int64_t n, const int32_t* d_ids, int64_t nt, const int64_t* d_offsets,
                           const int32_t* d_nbr, double radius, double* d_area, double* d_reach, void* stream);
 

@@ -1,6 +1,6 @@
-"""GPU: randomised parity sweep of k-NN, radius query and reference distance against the oracle on uneven node
-sets (clusters, latitude bands, polar caps, the date line; 1 to 20,000 sources) -- tools/fuzz_parity.py, which
-also runs longer sweeps from the command line."""
+"""GPU: randomised parity sweeps against the oracle on uneven node sets (clusters, latitude bands, polar caps, the
+date line): k-NN, radius query and reference distance (tools/fuzz_parity.py), spherical Voronoi cell areas
+(tools/fuzz_voronoi.py).  The tools also run longer sweeps from the command line."""
 import importlib.util
 from pathlib import Path
 
@@ -9,8 +9,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _tool(name):
+    spec = importlib.util.spec_from_file_location(name, Path(__file__).resolve().parents[1] / "tools" / f"{name}.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def test_randomised_parity_sweep(device):
-    spec = importlib.util.spec_from_file_location("fuzz_parity", Path(__file__).resolve().parents[1] / "tools" / "fuzz_parity.py")
-    fuzz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fuzz)
-    assert fuzz.run(80, seed0=1000) == 0
+    assert _tool("fuzz_parity").run(80, seed0=1000) == 0
+
+
+def test_randomised_voronoi_sweep(device):
+    """Cell areas against scipy on uneven node sets: agreement to 1e-7 wherever scipy's own result is sound,
+    the same kind of error where both refuse, a clear refusal for cells that span a hemisphere."""
+    assert _tool("fuzz_voronoi").run(120, seed0=2000) == 0
