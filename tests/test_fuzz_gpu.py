@@ -1,6 +1,6 @@
 """GPU: randomised parity sweeps against the oracle on uneven node sets (clusters, latitude bands, polar caps, the
 date line): k-NN, radius query and reference distance (tools/fuzz_parity.py), spherical Voronoi cell areas
-(tools/fuzz_voronoi.py).  The tools also run longer sweeps from the command line."""
+(tools/fuzz_voronoi.py), edge attributes (tools/fuzz_attrs.py), meshes and multi-scale edges (tools/fuzz_mesh.py).  The tools also run longer sweeps from the command line."""
 import importlib.util
 from pathlib import Path
 
@@ -24,3 +24,14 @@ def test_randomised_voronoi_sweep(device):
     """Cell areas against scipy on uneven node sets: agreement to 1e-7 wherever scipy's own result is sound,
     the same kind of error where both refuse, a clear refusal for cells that span a hemisphere."""
     assert _tool("fuzz_voronoi").run(120, seed0=2000) == 0
+
+
+def test_randomised_attribute_sweep(device):
+    """EdgeLength / EdgeDirection on arbitrary edge lists (unsorted targets, runs of any length, poles, long edges)."""
+    assert _tool("fuzz_attrs").run(60, seed0=3000) == 0
+
+
+def test_randomised_mesh_sweep(device):
+    """TriNodes / LimitedAreaTriNodes / StretchedTriNodes and their multi-scale edges for random regions,
+    margins, resolutions and hop counts."""
+    assert _tool("fuzz_mesh").run(40, seed0=4000) == 0
