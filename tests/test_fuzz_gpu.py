@@ -35,3 +35,9 @@ def test_randomised_mesh_sweep(device):
     """TriNodes / LimitedAreaTriNodes / StretchedTriNodes and their multi-scale edges for random regions,
     margins, resolutions and hop counts."""
     assert _tool("fuzz_mesh").run(40, seed0=4000) == 0
+
+
+def test_randomised_primitive_sweep(device):
+    """unique / sort / compact / gather / remap / mark / invert against numpy; masked KNNEdges and
+    RemoveUnconnectedNodes against the oracle."""
+    assert _tool("fuzz_ops").run(60, seed0=5000) == 0
