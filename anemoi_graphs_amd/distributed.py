@@ -8,8 +8,7 @@ Rank r owns band r:
   mesh, which is tiny and replicated -> no exchange;
 * encoder (CutOffEdges data -> hidden): targets = the hidden nodes whose latitude falls in the
   band (a contiguous id range, hidden nodes are latitude-sorted), sources = the rank's data band
-  widened by the cut-off radius: the missing rows come from the two adjacent ranks (a one-hop halo
-  exchange; if the radius exceeded a whole band the bands would be all-gathered instead);
+  widened by the cut-off radius;
 * processor (MultiScaleEdges) and TriNodes: replicated, they are a few MB;
 * the edge lists are all-gathered (variable length, rank order = target order, so the
   concatenation is already the single-GPU edge list); the all-gathers run asynchronously while the
@@ -17,9 +16,13 @@ Rank r owns band r:
   gathered edge lists by every rank: 8 B/edge of edge ids travel over xGMI instead of 20 B/edge, and
   the values are bit-identical to the single-GPU build by construction.
 
-Collectives: one MAX all-reduce is avoided by replicating the reference-distance query; halo
-point-to-point send/recv with the two neighbours; all-gather of counts and of the padded edge
-chunks.  With the ``gloo`` backend (CPU tests) tensors are staged through host memory.
+Every rank is given the complete coordinate array (53 MB for O1280), so the widened source band is a
+slice of it and no coordinates travel (``exchange_halo=True`` treats them as sharded instead: the
+missing rows come from the two adjacent ranks by point-to-point send/recv, or from an all-gather of the
+bands when the radius is wider than a band).  Collectives of a build: the edge counts of the encoder
+bands (host integers, over a host-side gloo group so that they neither wait for queued device work
+nor occupy the stream), and the all-gathers of the edge lists into their final place.  With the
+``gloo`` backend (CPU tests) tensors are staged through host memory.
 """
 from __future__ import annotations
 
@@ -36,6 +39,11 @@ class Communicator:
     def __init__(self, dist, rank: int, world_size: int):
         self.dist, self.rank, self.world = dist, rank, world_size
         self.host_staged = dist is not None and dist.get_backend() == "gloo"
+        # Edge counts and the like are host integers: they travel over a host-side (gloo) group, so that the
+        # exchange neither waits for the device work queued before it nor puts a kernel into the stream.
+        self.host_group = None
+        if dist is not None and not self.host_staged:
+            self.host_group = dist.new_group(backend="gloo")
 
     def _out(self, t: torch.Tensor) -> torch.Tensor:
         return t.cpu() if self.host_staged else t
@@ -44,10 +52,20 @@ class Communicator:
         return t.to(device) if self.host_staged else t
 
     def all_gather_sizes(self, values: list[int], device) -> torch.Tensor:
-        mine = torch.tensor(values, dtype=torch.int64, device="cpu" if self.host_staged else device)
-        out = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(out, mine)
-        return torch.stack(out).cpu()
+        return self.all_gather_sizes_async(values, device)()
+
+    def all_gather_sizes_async(self, values: list[int], device):
+        """Start the exchange of a few host integers per rank; the returned callable waits and gives the
+        [world, len(values)] table on the host."""
+        mine = torch.tensor(values, dtype=torch.int64)
+        out = torch.empty((self.world, len(values)), dtype=torch.int64)
+        work = self.dist.all_gather_into_tensor(out.reshape(-1), mine, group=self.host_group, async_op=True)
+
+        def finish() -> torch.Tensor:
+            work.wait()
+            return out
+
+        return finish
 
     def all_gather_rows(self, t: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
         """Concatenate variable-length chunks [n_r, ...] of every rank along dim 0 in rank order."""
@@ -141,7 +159,7 @@ class ShardedGraphBuilder:
     def __init__(self, data_x: torch.Tensor, resolution: int, cutoff_factor: float = 0.6,
                  num_nearest_neighbours: int = 3, x_hops: int = 1, rank: int = 0, world_size: int = 1, dist=None,
                  backend=None, attributes: bool = True, edge_length_norm: str | None = "unit-max",
-                 edge_direction_norm: str | None = None):
+                 edge_direction_norm: str | None = None, exchange_halo: bool = False):
         self.backend = _hip_ops if backend is None else backend
         self.resolution = resolution
         self.cutoff_factor = cutoff_factor
@@ -157,18 +175,20 @@ class ShardedGraphBuilder:
         self.data_full = data_x if world_size == 1 else None
         self.data_all = data_x  # every rank is given the complete coordinate array (53 MB for O1280)
         self.data_local = data_x[lo:hi].contiguous()
+        self.exchange_halo = exchange_halo
         if world_size > 1 or dist is not None:  # (a process group of one rank still takes the sharded route)
-            lat = self.data_local[:, 0]
+            lat = data_x[:, 0]
             if lat.numel() > 1 and bool((lat[1:] > lat[:-1]).any()):
                 raise ValueError("latitude-band sharding needs data nodes ordered north -> south")
             self.comm = Communicator(dist, rank, world_size)
-            # cut latitudes: the first latitude of every band (band r holds lat <= cut[r])
-            ends = self.comm.all_gather_rows(self.data_local[[0, -1], 0].reshape(1, 2), counts=[1] * world_size)
-            self.first_lat = ends[:, 0].cpu().tolist()
-            self.last_lat = ends[:, 1].cpu().tolist()
+            # cut latitudes: the first latitude of every band (band r holds lat <= first_lat[r]); every rank
+            # holds the complete coordinate array, so they are read, not exchanged
+            firsts = torch.as_tensor([min(b, self.n_data - 1) for b in self.bounds[:-1]], device=data_x.device)
+            self.first_lat = lat[firsts].cpu().tolist()
             # search keys of the band limits, kept on the device (ascending = negated latitudes)
             dev = self.data_local.device
             self.neg_lat = (-self.data_local[:, 0]).contiguous()
+            self.neg_lat_all = (-lat).contiguous()
             self.neg_upper = torch.tensor(-self.first_lat[rank], dtype=lat.dtype, device=dev)
             self.neg_lower = torch.tensor(-self.first_lat[min(rank + 1, world_size - 1)], dtype=lat.dtype, device=dev)
         else:
@@ -221,45 +241,56 @@ class ShardedGraphBuilder:
         # ---- encoder: hidden targets of my band, data sources = my band + halo
         # (band limits by binary search on the device; one host synchronisation for all of them)
         radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
-        reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-7
+        reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
         nd = self.data_local.shape[0]
         neg_hlat = (-hidden[:, 0]).contiguous()
         zero = torch.zeros((), dtype=torch.int64, device=dev)
         # hidden nodes are latitude-descending: band r = lat in (first_lat[r+1], first_lat[r]]
         h_lo = torch.searchsorted(neg_hlat, self.neg_upper.to(neg_hlat.dtype)) if r > 0 else zero
         h_hi = torch.searchsorted(neg_hlat, self.neg_lower.to(neg_hlat.dtype)) if r < W - 1 else zero + nh
-        # rows my neighbours need from me: their hidden band widened by the reach
-        if r > 0:  # the north neighbour's targets reach down to first_lat[r] - reach
-            q = (-(self.first_lat[r] - reach_t)).to(self.neg_lat.dtype)
-            n_north = torch.searchsorted(self.neg_lat, q, right=True)
+        if not self.exchange_halo:
+            # the sources of my targets: every data node within the reach of my latitude band -- a slice of
+            # the coordinate array every rank holds, however many bands it spans
+            keys = self.neg_lat_all
+            s_lo = torch.searchsorted(keys, (-(self.first_lat[r] + reach_t)).to(keys.dtype)) if r > 0 else zero
+            s_hi = (torch.searchsorted(keys, (-(self.first_lat[r + 1] - reach_t)).to(keys.dtype), right=True)
+                    if r < W - 1 else zero + self.n_data)
+            vals = torch.stack([radius_t] + [v.reshape(()).double() for v in (h_lo, h_hi, s_lo, s_hi)]).tolist()
+            radius = vals[0]
+            h_lo, h_hi, s_lo, s_hi = (int(v) for v in vals[1:])
+            sources = self.data_all[s_lo:s_hi]
+            g_lo = s_lo
         else:
-            n_north = zero
-        if r < W - 1:  # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
-            q = (-(self.first_lat[r + 1] + reach_t)).to(self.neg_lat.dtype)
-            s_start = torch.searchsorted(self.neg_lat, q, right=False)
-        else:
-            s_start = zero + nd
-        vals = torch.stack([radius_t] + [v.reshape(()).double() for v in (h_lo, h_hi, n_north, s_start)]).tolist()
-        radius = vals[0]
-        h_lo, h_hi, n_north, s_start = (int(v) for v in vals[1:])
-        one_hop = (r == 0 or n_north < nd) and (r == W - 1 or s_start > 0)
-        sizes = comm.all_gather_sizes([int(one_hop), n_north, nd - s_start], dev)
-        if bool(sizes[:, 0].min()):
-            from_north, from_south = comm.exchange_halo(
-                self.data_local[:n_north], self.data_local[s_start:],
-                int(sizes[r - 1, 2]) if r > 0 else 0, int(sizes[r + 1, 1]) if r < W - 1 else 0)
-            sources = torch.cat([from_north, self.data_local, from_south], dim=0) if W > 1 else self.data_local
-            g_lo = self.d_lo - from_north.shape[0]
-        else:  # radius wider than a band: every rank takes all data rows
-            sources = comm.all_gather_rows(self.data_local)
-            g_lo = 0
+            # coordinates treated as sharded: the rows beyond my band come from the neighbouring ranks
+            if r > 0:  # the north neighbour's targets reach down to first_lat[r] - reach
+                q = (-(self.first_lat[r] - reach_t)).to(self.neg_lat.dtype)
+                n_north = torch.searchsorted(self.neg_lat, q, right=True)
+            else:
+                n_north = zero
+            if r < W - 1:  # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
+                q = (-(self.first_lat[r + 1] + reach_t)).to(self.neg_lat.dtype)
+                s_start = torch.searchsorted(self.neg_lat, q, right=False)
+            else:
+                s_start = zero + nd
+            vals = torch.stack([radius_t] + [v.reshape(()).double() for v in (h_lo, h_hi, n_north, s_start)]).tolist()
+            radius = vals[0]
+            h_lo, h_hi, n_north, s_start = (int(v) for v in vals[1:])
+            one_hop = (r == 0 or n_north < nd) and (r == W - 1 or s_start > 0)
+            sizes = comm.all_gather_sizes([int(one_hop), n_north, nd - s_start], dev)
+            if bool(sizes[:, 0].min()):
+                from_north, from_south = comm.exchange_halo(
+                    self.data_local[:n_north], self.data_local[s_start:],
+                    int(sizes[r - 1, 2]) if r > 0 else 0, int(sizes[r + 1, 1]) if r < W - 1 else 0)
+                sources = torch.cat([from_north, self.data_local, from_south], dim=0) if W > 1 else self.data_local
+                g_lo = self.d_lo - from_north.shape[0]
+            else:  # radius wider than a band: every rank takes all data rows
+                sources = comm.all_gather_rows(self.data_local)
+                g_lo = 0
         targets = hidden[h_lo:h_hi].contiguous()
         enc = be.radius_edges(sources, targets, radius)
         enc[0] += g_lo
         enc[1] += h_lo
-        enc_counts = comm.all_gather_sizes([enc.shape[1]], dev)[:, 0].tolist()
-        enc_all = torch.empty((2, sum(enc_counts)), dtype=enc.dtype, device=dev)
-        enc_gather = comm.all_gather_rows_async([enc[0], enc[1]], enc_counts, out=[enc_all[0], enc_all[1]])
+        enc_counts_ready = comm.all_gather_sizes_async([enc.shape[1]], dev)  # read after the decoder is queued
 
         # ---- decoder: my data band as targets, replicated hidden sources; only the source ids travel
         # (the target row of a k-NN edge list is 0,0,0,1,1,1,... whatever the band)
@@ -267,7 +298,11 @@ class ShardedGraphBuilder:
         band_sizes = [(self.bounds[i + 1] - self.bounds[i]) * self.k for i in range(W)]
         dec_all = torch.empty((2, self.n_data * self.k), dtype=torch.int32, device=dev)
         dec_gather = comm.all_gather_rows_async([ids], band_sizes, out=[dec_all[0]])
-        dec_all[1] = be.row_ids(self.n_data, self.k, dev)
+        be.row_ids(self.n_data, self.k, dev, out=dec_all[1])
+
+        enc_counts = enc_counts_ready()[:, 0].tolist()
+        enc_all = torch.empty((2, sum(enc_counts)), dtype=enc.dtype, device=dev)
+        enc_gather = comm.all_gather_rows_async([enc[0], enc[1]], enc_counts, out=[enc_all[0], enc_all[1]])
 
         # ---- processor: replicated, while the edge lists travel
         proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,

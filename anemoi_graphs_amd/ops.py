@@ -94,12 +94,15 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int) -> torch.Tensor:
     return edge_index
 
 
-def row_ids(rows: int, k: int, device: torch.device) -> torch.Tensor:
-    """int32 [rows*k]: 0 (k times), 1 (k times), ... -- the target row of a k-NN edge list."""
+def row_ids(rows: int, k: int, device: torch.device, out: torch.Tensor | None = None) -> torch.Tensor:
+    """int32 [rows*k]: 0 (k times), 1 (k times), ... -- the target row of a k-NN edge list
+    (written into ``out``, a contiguous int32 device tensor of that length, when given)."""
     lib = _lib.load()
     dev = torch.device(device)
     with torch.cuda.device(dev):
-        out = torch.empty(rows * k, dtype=torch.int32, device=dev)
+        if out is None:
+            out = torch.empty(rows * k, dtype=torch.int32, device=dev)
+        assert out.dtype == torch.int32 and out.is_contiguous() and out.numel() == rows * k
         _lib.check(lib.ag_fill_row_ids(_ptr(out), rows, k, _stream(dev)), "ag_fill_row_ids")
     return out
 

@@ -37,8 +37,12 @@ def knn(src, tgt, k):
     return torch.from_numpy(e[0].reshape(len(_np(tgt)), k).copy())
 
 
-def row_ids(rows, k, device=None):
-    return torch.arange(rows, dtype=torch.int32).repeat_interleave(k)
+def row_ids(rows, k, device=None, out=None):
+    ids = torch.arange(rows, dtype=torch.int32).repeat_interleave(k)
+    if out is None:
+        return ids
+    out.copy_(ids)
+    return out
 
 
 def multiscale_edges(max_resolution, levels, x_hops, rank, level_edges=None, active=None):

@@ -20,21 +20,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(data, rank, world, d, resolution, factor):
+def _build(data, rank, world, d, resolution, factor, exchange=False):
     from tests import oracle_backend
 
     b = ShardedGraphBuilder(torch.from_numpy(data), resolution, cutoff_factor=factor, num_nearest_neighbours=3,
                             x_hops=1, rank=rank, world_size=world, dist=d, backend=oracle_backend,
-                            edge_length_norm="unit-max", edge_direction_norm="unit-std")
+                            edge_length_norm="unit-max", edge_direction_norm="unit-std", exchange_halo=exchange)
     return b._build_sharded() if world > 1 else None
 
 
-def _worker(rank, world, port, grid, resolution, factor, out_dir):
+def _worker(rank, world, port, grid, resolution, factor, out_dir, exchange=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         data = grids.named(grid)
-        g = _build(data, rank, world, dist, resolution, factor)
+        g = _build(data, rank, world, dist, resolution, factor, exchange)
         out = {}
         for name in (("data", "to", "hidden"), ("hidden", "to", "data"), ("hidden", "to", "hidden")):
             key = "_".join(name)
@@ -68,11 +68,16 @@ def _single(grid, resolution, factor):
     return out
 
 
-@pytest.mark.parametrize("grid,resolution,factor,world", [("o16", 2, 0.6, 2), ("reg10.0", 1, 0.6, 2), ("o16", 2, 4.0, 2), ("o16", 2, 0.6, 3)])
-def test_sharded_build_equals_single(tmp_path, grid, resolution, factor, world):
-    """Third case: a radius wider than a band forces the all-gather fallback instead of the halo."""
+@pytest.mark.parametrize("grid,resolution,factor,world,exchange", [
+    ("o16", 2, 0.6, 2, False), ("reg10.0", 1, 0.6, 2, False), ("o16", 2, 4.0, 2, False), ("o16", 2, 0.6, 3, False),
+    ("o16", 2, 0.6, 3, True), ("o16", 2, 4.0, 2, True),
+])
+def test_sharded_build_equals_single(tmp_path, grid, resolution, factor, world, exchange):
+    """``exchange``: the coordinates treated as sharded (halo rows sent between neighbouring ranks; with the
+    factor 4.0 the radius is wider than a band, which forces the all-gather of the bands) instead of sliced
+    from the replicated array."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path), exchange), nprocs=world, join=True)
     want = _single(grid, resolution, factor)
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
