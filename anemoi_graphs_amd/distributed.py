@@ -42,8 +42,12 @@ class Communicator:
         # Edge counts and the like are host integers: they travel over a host-side (gloo) group, so that the
         # exchange neither waits for the device work queued before it nor puts a kernel into the stream.
         self.host_group = None
+        self.sizes_on_device = False
         if dist is not None and not self.host_staged:
-            self.host_group = dist.new_group(backend="gloo")
+            try:
+                self.host_group = dist.new_group(backend="gloo")
+            except Exception:  # noqa: BLE001 - no usable host transport: the few integers go through RCCL instead
+                self.sizes_on_device = True
 
     def _out(self, t: torch.Tensor) -> torch.Tensor:
         return t.cpu() if self.host_staged else t
@@ -57,13 +61,14 @@ class Communicator:
     def all_gather_sizes_async(self, values: list[int], device):
         """Start the exchange of a few host integers per rank; the returned callable waits and gives the
         [world, len(values)] table on the host."""
-        mine = torch.tensor(values, dtype=torch.int64)
-        out = torch.empty((self.world, len(values)), dtype=torch.int64)
+        where = device if self.sizes_on_device else "cpu"
+        mine = torch.tensor(values, dtype=torch.int64, device=where)
+        out = torch.empty((self.world, len(values)), dtype=torch.int64, device=where)
         work = self.dist.all_gather_into_tensor(out.reshape(-1), mine, group=self.host_group, async_op=True)
 
         def finish() -> torch.Tensor:
             work.wait()
-            return out
+            return out.cpu()
 
         return finish
 
