@@ -28,6 +28,7 @@
 #include "ag_common.hpp"
 
 #define AG_ATTR_CHUNK 128  // edges per wave iteration (two per lane)
+#define AG_ATTR_MAX_BLOCKS (256 * 8)
 
 __device__ __forceinline__ float ag_np_sin_f32(float x) {
   float s, c;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
                                                             const int32_t* __restrict__ es,
                                                             const int32_t* __restrict__ et, int64_t E, int flags,
                                                             float* __restrict__ out_len, float2* __restrict__ out_dir,
-                                                            const AgAtanCoef K) {
+                                                            unsigned* __restrict__ len_range, const AgAtanCoef K) {
   __shared__ AgAttrRuns R_all[4];
   const bool rotated = (flags & AG_ATTR_ROTATED) != 0 && out_dir != nullptr;
   const bool want_len = out_len != nullptr, want_dir = out_dir != nullptr;
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     }
     return g;
   };
+  // running range of the lengths this lane has written, as bit patterns: lengths are >= +0 (or NaN),
+  // so their bits order like the values, and NaN ranks above every number as numpy's max / min have it
+  unsigned hi_bits = 0u, lo_inv_bits = 0u;
   auto process = [&](int64_t chunk, const Ends& g) {
     const int64_t base = chunk * AG_ATTR_CHUNK;
     const int64_t left = E - base;
@@ -284,7 +288,12 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
       float len;
       float2 dir;
       ag_attr_edge(g.sp[j], R, run[j], rotated, want_len, want_dir, K, &len, &dir);
-      if (want_len) len_c[j * 64 + lane] = len;
+      if (want_len) {
+        len_c[j * 64 + lane] = len;
+        const unsigned b = __float_as_uint(len);
+        hi_bits = max(hi_bits, b);
+        lo_inv_bits = max(lo_inv_bits, (b > 0x7f800000u) ? 0u : ~b);  // (a NaN is seen through the maximum)
+      }
       if (want_dir) dir_c[j * 64 + lane] = dir;
     }
     ag_lds_wave_sync();  // the staged runs are overwritten by the next chunk
@@ -304,17 +313,75 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     ids = fetch_ids(chunk + 3 * nwaves);
     process(chunk + nwaves, gb);
   }
+  if (len_range != nullptr && want_len) {
+    // every wave that had a chunk leaves its range in a slot of its own (atomics of thousands of waves on
+    // one word are far slower than the kernel); ag_len_range_finish_kernel folds the slots
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      hi_bits = max(hi_bits, static_cast<unsigned>(__shfl_xor(static_cast<int>(hi_bits), o, 64)));
+      lo_inv_bits = max(lo_inv_bits, static_cast<unsigned>(__shfl_xor(static_cast<int>(lo_inv_bits), o, 64)));
+    }
+    if (lane == 0) reinterpret_cast<uint2*>(len_range)[1 + wave_global] = make_uint2(hi_bits, lo_inv_bits);
+  }
 }
+
+// slots 1 .. nslots of the waves -> words 0 and 1
+__global__ __launch_bounds__(1024) void ag_len_range_finish_kernel(unsigned* __restrict__ range, int nslots) {
+  __shared__ uint2 sh[16];
+  unsigned hi = 0u, lo_inv = 0u;
+  const uint2* slots = reinterpret_cast<const uint2*>(range) + 1;
+  for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
+    const uint2 v = slots[i];
+    hi = max(hi, v.x);
+    lo_inv = max(lo_inv, v.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi = max(hi, static_cast<unsigned>(__shfl_xor(static_cast<int>(hi), o, 64)));
+    lo_inv = max(lo_inv, static_cast<unsigned>(__shfl_xor(static_cast<int>(lo_inv), o, 64)));
+  }
+  if (ag_lane() == 0) sh[threadIdx.x >> 6] = make_uint2(hi, lo_inv);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      hi = max(hi, sh[w].x);
+      lo_inv = max(lo_inv, sh[w].y);
+    }
+    range[0] = hi;
+    range[1] = lo_inv;
+  }
+}
+
+extern "C" int ag_edge_attrs_range(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt,
+                                   const int32_t* d_edge_src, const int32_t* d_edge_tgt, int64_t E, int flags,
+                                   float* d_len, float* d_dir, uint32_t* d_len_range, void* stream) {
+  AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool want_range = d_len_range != nullptr && d_len != nullptr;
+  const bool empty = E == 0 || (d_len == nullptr && d_dir == nullptr);
+  if (!empty) {
+    AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
+    const int blocks = ag_blocks(E, 4 * AG_ATTR_CHUNK, AG_ATTR_MAX_BLOCKS);
+    AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(blocks), dim3(256), s, reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), want_range ? d_len_range : nullptr, AG_ATAN_COEF);
+    AG_LAUNCH_CHECK();
+  }
+  if (d_len_range != nullptr) {
+    // the waves that had a chunk: all of them, or one per chunk when the list is shorter than the grid
+    const int64_t nchunks = (E + AG_ATTR_CHUNK - 1) / AG_ATTR_CHUNK;
+    const int64_t nwaves = int64_t(ag_blocks(E, 4 * AG_ATTR_CHUNK, AG_ATTR_MAX_BLOCKS)) * 4;
+    const int nslots = (empty || !want_range) ? 0 : static_cast<int>(nchunks < nwaves ? nchunks : nwaves);
+    AG_KERNEL("ag_len_range_finish_kernel", ag_len_range_finish_kernel, dim3(1), dim3(1024), s, d_len_range, nslots);
+    AG_LAUNCH_CHECK();
+  }
+  return AG_OK;
+}
+
+extern "C" size_t ag_len_range_words(void) { return 2 * (1 + size_t(AG_ATTR_MAX_BLOCKS) * 4); }
 
 extern "C" int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt,
                              const int32_t* d_edge_src, const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len,
                              float* d_dir, void* stream) {
-  AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
-  if (E == 0 || (d_len == nullptr && d_dir == nullptr)) return AG_OK;
-  AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
-  AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(ag_blocks(E, 4 * AG_ATTR_CHUNK, 256 * 8)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), AG_ATAN_COEF);
-  AG_LAUNCH_CHECK();
-  return AG_OK;
+  return ag_edge_attrs_range(d_src_x, ns, d_tgt_x, nt, d_edge_src, d_edge_tgt, E, flags, d_len, d_dir, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,10 +508,19 @@ __global__ __launch_bounds__(256) void ag_reduce_final_kernel(const AgStats* __r
 }
 
 __global__ __launch_bounds__(256) void ag_normalise_apply_kernel(float* __restrict__ v, int64_t n, int norm, int invert,
-                                                                 const AgStats* __restrict__ stats) {
+                                                                 const AgStats* __restrict__ stats,
+                                                                 const unsigned* __restrict__ range) {
   float scale = 1.0f, shift = 0.0f;
   bool skip = false;
-  if (norm == 1) scale = static_cast<float>(stats->sum);
+  if (range != nullptr) {  // maximum and minimum known beforehand (bit patterns, the minimum complemented)
+    const float vmax = __uint_as_float(range[0]);
+    const float vmin = (vmax != vmax) ? vmax : __uint_as_float(~range[1]);
+    if (norm == 3) scale = vmax;
+    else if (norm == 4) {
+      shift = vmin;
+      scale = vmax - vmin;
+    } else skip = true;
+  } else if (norm == 1) scale = static_cast<float>(stats->sum);
   else if (norm == 2) scale = static_cast<float>(sqrt(stats->sumsq));
   else if (norm == 3) scale = static_cast<float>(stats->vmax);
   else if (norm == 4) {
@@ -592,7 +668,19 @@ extern "C" int ag_normalise(float* d_values, int64_t n, int norm, int invert, vo
       AG_LAUNCH_CHECK();
     }
   }
-  AG_KERNEL("ag_normalise_apply_kernel", ag_normalise_apply_kernel, dim3(ag_blocks(n, 256 * 8, 1 << 14)), dim3(256), s, d_values, n, norm, invert, stats);
+  AG_KERNEL("ag_normalise_apply_kernel", ag_normalise_apply_kernel, dim3(ag_blocks(n, 256 * 8, 1 << 14)), dim3(256), s, d_values, n, norm, invert, stats, static_cast<const unsigned*>(nullptr));
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+extern "C" int ag_normalise_range(float* d_values, int64_t n, int norm, int invert, const uint32_t* d_range,
+                                  void* stream) {
+  AG_REQUIRE(norm == 0 || norm == 3 || norm == 4, "ag_normalise_range: normalisation %d does not follow from a range", norm);
+  AG_REQUIRE(n >= 0, "ag_normalise_range: negative size");
+  if (n == 0 || (norm == 0 && !invert)) return AG_OK;
+  AG_REQUIRE(d_values && d_range, "ag_normalise_range: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AG_KERNEL("ag_normalise_apply_kernel", ag_normalise_apply_kernel, dim3(ag_blocks(n, 256 * 8, 1 << 14)), dim3(256), s, d_values, n, norm, invert, static_cast<const AgStats*>(nullptr), d_range);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

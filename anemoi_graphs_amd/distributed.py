@@ -226,11 +226,15 @@ class ShardedGraphBuilder:
 
     # ---------------------------------------------------------------------------------- sharded
     def _attrs(self, src_x, tgt_x, edge_index):
+        if self.backend is _hip_ops:  # the kernel reports the range of the lengths for their normalisation
+            length, direction, len_range = self.backend.edge_attrs(src_x, tgt_x, edge_index, len_range=True)
+            return length.reshape(-1, 1), direction, len_range
         length, direction = self.backend.edge_attrs(src_x, tgt_x, edge_index)
-        return length.reshape(-1, 1), direction
+        return length.reshape(-1, 1), direction, None
 
-    def _finish_attrs(self, store, length, direction):
-        store["edge_length"] = self.backend.normalise_(length.contiguous(), self.len_norm)
+    def _finish_attrs(self, store, length, direction, len_range=None):
+        extra = {} if len_range is None else {"value_range": len_range}
+        store["edge_length"] = self.backend.normalise_(length.contiguous(), self.len_norm, **extra)
         store["edge_dirs"] = self.backend.normalise_(direction.contiguous(), self.dir_norm)
 
     def _build_sharded(self) -> HeteroData:

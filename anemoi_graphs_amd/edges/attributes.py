@@ -53,19 +53,20 @@ def compute_fused(graph: HeteroData, edges_name: tuple[str, str, str], attribute
     source_name, _, target_name = edges_name
     lengths = [a for a in attributes.values() if type(a) is EdgeLength]
     directions = [a for a in attributes.values() if type(a) is EdgeDirection]
-    raw_len = raw_dir = None
+    raw_len = raw_dir = len_range = None
     if lengths and directions and len({d.luse_rotated_features for d in directions}) == 1:
         for a in attributes.values():
             a.check_nodes(graph, edges_name)
         edge_index = graph[edges_name].edge_index
-        raw_len, raw_dir = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index,
-                                          rotated=directions[0].luse_rotated_features)
+        # (the kernel also reports the range of the lengths: unit-max / unit-range need no reduction pass)
+        raw_len, raw_dir, len_range = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index,
+                                                     rotated=directions[0].luse_rotated_features, len_range=True)
     out = {}
     n_len, n_dir = len(lengths), len(directions)
     for name, a in attributes.items():
         if raw_len is not None and type(a) is EdgeLength:
             n_len -= 1  # normalisation is in place: all but the last user work on a copy of the raw values
-            out[name] = a.post_process(raw_len.clone() if n_len else raw_len)
+            out[name] = a.post_process(raw_len.clone() if n_len else raw_len, value_range=len_range)
         elif raw_dir is not None and type(a) is EdgeDirection:
             n_dir -= 1
             out[name] = a.post_process(raw_dir.clone() if n_dir else raw_dir)
@@ -101,7 +102,8 @@ class EdgeLength(BaseEdgeAttribute):
         length, _ = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index, want_dir=False)
         return length
 
-    def post_process(self, values: torch.Tensor) -> torch.Tensor:
+    def post_process(self, values: torch.Tensor, value_range: torch.Tensor | None = None) -> torch.Tensor:
+        """``value_range``: the range of ``values`` when the kernel that produced them reported it."""
         if values.ndim == 1:
             values = values[:, None]
-        return place(ops.normalise_(values.contiguous(), self.norm, invert=self.invert))
+        return place(ops.normalise_(values.contiguous(), self.norm, invert=self.invert, value_range=value_range))

@@ -306,8 +306,10 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
 
 
 def edge_attrs(src_x: torch.Tensor, tgt_x: torch.Tensor, edge_index: torch.Tensor, want_len: bool = True,
-               want_dir: bool = True, rotated: bool = True):
-    """Raw EdgeLength [E] and EdgeDirection [E,2] float32 values of an edge list."""
+               want_dir: bool = True, rotated: bool = True, len_range: bool = False):
+    """Raw EdgeLength [E] and EdgeDirection [E,2] float32 values of an edge list.  With ``len_range``
+    a third result: the device-side range of the lengths (2 words, see ag_edge_attrs_range) that
+    ``normalise_`` takes as ``value_range`` to skip its reduction pass."""
     lib = _lib.load()
     dev = device_of(edge_index, src_x, tgt_x)
     src_x, tgt_x = coords(src_x, dev), coords(tgt_x, dev)
@@ -316,16 +318,22 @@ def edge_attrs(src_x: torch.Tensor, tgt_x: torch.Tensor, edge_index: torch.Tenso
     with torch.cuda.device(dev):
         length = torch.empty(num_edges, dtype=torch.float32, device=dev) if want_len else None
         direction = torch.empty((num_edges, 2), dtype=torch.float32, device=dev) if want_dir else None
+        rng = (torch.empty(lib.ag_len_range_words(), dtype=torch.int32, device=dev)
+               if (len_range and want_len) else None)
         _lib.check(
-            lib.ag_edge_attrs(_ptr(src_x), src_x.shape[0], _ptr(tgt_x), tgt_x.shape[0], _ptr(e[0]), _ptr(e[1]),
-                              num_edges, 1 if rotated else 0, _ptr(length), _ptr(direction), _stream(dev)),
-            "ag_edge_attrs",
+            lib.ag_edge_attrs_range(_ptr(src_x), src_x.shape[0], _ptr(tgt_x), tgt_x.shape[0], _ptr(e[0]), _ptr(e[1]),
+                                    num_edges, 1 if rotated else 0, _ptr(length), _ptr(direction), _ptr(rng),
+                                    _stream(dev)),
+            "ag_edge_attrs_range",
         )
-    return length, direction
+    return (length, direction, rng) if len_range else (length, direction)
 
 
-def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False) -> torch.Tensor:
-    """In-place global normalisation of a float32 device tensor (all elements reduced together)."""
+def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False,
+               value_range: torch.Tensor | None = None) -> torch.Tensor:
+    """In-place global normalisation of a float32 device tensor (all elements reduced together).
+    ``value_range``: the range of exactly these values as reported by ``edge_attrs(len_range=True)``;
+    the normalisations that follow from a range (unit-max, unit-range) then take one pass."""
     if norm not in NORMS:
         raise ValueError(
             f"Attribute normalisation \"{norm}\" is not valid. Options are: 'l1', 'l2', 'unit-max' or 'unit-std'."
@@ -336,6 +344,11 @@ def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False) -> 
     dev = values.device
     assert values.dtype == torch.float32 and values.is_contiguous()
     n = values.numel()
+    if value_range is not None and NORMS[norm] in (0, 3, 4):
+        with torch.cuda.device(dev):
+            _lib.check(lib.ag_normalise_range(_ptr(values), n, NORMS[norm], int(invert), _ptr(value_range), _stream(dev)),
+                       "ag_normalise_range")
+        return values
     with torch.cuda.device(dev):
         ws = _workspace(lib.ag_normalise_workspace_bytes(n), dev)
         _lib.check(lib.ag_normalise(_ptr(values), n, NORMS[norm], int(invert), _ptr(ws), ws.numel(), _stream(dev)),

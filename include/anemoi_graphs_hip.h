@@ -153,6 +153,21 @@ int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, in
 int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt, const int32_t* d_edge_src,
                   const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len, float* d_dir, void* stream);
 
+/* ag_edge_attrs that also reports the range of the lengths it wrote, so that the `unit-max` /
+ * `unit-range` normalisation of EdgeLength (normalise.py:45-48: values.max(), values.min()) needs no
+ * pass over the values of its own.  d_len_range: ag_len_range_words() 32-bit words, written by the
+ * call (no need to clear them): [0] = bits of the largest length, [1] = complement of the bits of
+ * the smallest, the rest scratch; a NaN length makes both NaN, as numpy's max / min do.
+ * NULL = plain ag_edge_attrs. */
+size_t ag_len_range_words(void);
+int ag_edge_attrs_range(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt, const int32_t* d_edge_src,
+                        const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len, float* d_dir,
+                        uint32_t* d_len_range, void* stream);
+
+/* ag_normalise for norm 3 (unit-max), 4 (unit-range) or 0 from a range reported by
+ * ag_edge_attrs_range: one pass, no workspace.  Same results as ag_normalise on NaN-free values. */
+int ag_normalise_range(float* d_values, int64_t n, int norm, int invert, const uint32_t* d_range, void* stream);
+
 /* Global normalisation of an attribute array in place.
  * Replaces NormaliserMixin.normalise (normalise.py:36-55) + the float32 cast and the
  * optional `1 - v` of EdgeLength.post_process (edges/attributes.py:33-40,150-157).

@@ -107,3 +107,30 @@ def test_normalise_any_alignment_and_length(device, offset, n, norm):
     got = ops.normalise_(t, norm).cpu().numpy()
     want = rp.post_process(full[offset:].reshape(-1, 1), norm)[:, 0]
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_edges", [1, 3, 127, 128, 129, 5000, 300001])
+def test_length_range_from_the_attribute_kernel(device, n_edges):
+    """The range of the lengths reported by the attribute kernel gives the unit-max / unit-range
+    normalisations (normalise.py:45-48) the same bits as the reduction pass over the values."""
+    rng = np.random.default_rng(n_edges)
+    x = np.stack([np.arcsin(rng.uniform(-1, 1, 4000)), rng.uniform(0, 2 * np.pi, 4000)], axis=1).astype(np.float32)
+    e = rng.integers(0, len(x), size=(2, n_edges)).astype(np.int32)
+    if n_edges > 3:
+        e[0, 2] = e[1, 2]  # a self edge: the minimum is exactly 0
+    xd, ed = torch.from_numpy(x).to(device), torch.from_numpy(e).to(device)
+    length, _, value_range = ops.edge_attrs(xd, xd, ed, len_range=True)
+    plain, _ = ops.edge_attrs(xd, xd, ed)
+    assert torch.equal(length, plain)
+    bits = value_range.cpu().numpy().view(np.uint32)
+    assert np.uint32(bits[0]) == length.cpu().numpy().max().view(np.uint32)
+    assert np.uint32(~bits[1]) == length.cpu().numpy().min().view(np.uint32)
+    for norm in (None, "unit-max", "unit-range"):
+        for invert in (False, True):
+            want = ops.normalise_(plain.clone().reshape(-1, 1), norm, invert)
+            got = ops.normalise_(length.clone().reshape(-1, 1), norm, invert, value_range=value_range)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (norm, invert)  # (0/0 = NaN for one edge)
+    # a normalisation that does not follow from the range takes the ordinary route
+    want = ops.normalise_(plain.clone().reshape(-1, 1), "l2")
+    got = ops.normalise_(length.clone().reshape(-1, 1), "l2", value_range=value_range)
+    assert torch.equal(got, want)
