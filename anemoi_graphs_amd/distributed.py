@@ -247,6 +247,16 @@ class ShardedGraphBuilder:
         graph["hidden"].node_type = "TriNodes"
         nh = hidden.shape[0]
 
+        # ---- decoder first: my data band as targets, replicated hidden sources; only the source ids travel
+        # (the target row of a k-NN edge list is 0,0,0,1,1,1,... whatever the band).  It needs nothing from
+        # the other ranks and its gather is the largest transfer of the build, so it is started before the
+        # reference distance and the encoder search, which then run while the ids travel.
+        ids = be.knn(hidden, self.data_local, self.k).reshape(-1)
+        band_sizes = [(self.bounds[i + 1] - self.bounds[i]) * self.k for i in range(W)]
+        dec_all = torch.empty((2, self.n_data * self.k), dtype=torch.int32, device=dev)
+        dec_gather = comm.all_gather_rows_async([ids], band_sizes, out=[dec_all[0]])
+        be.row_ids(self.n_data, self.k, dev, out=dec_all[1])
+
         # ---- encoder: hidden targets of my band, data sources = my band + halo
         # (band limits by binary search on the device; one host synchronisation for all of them)
         radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
@@ -299,19 +309,7 @@ class ShardedGraphBuilder:
         enc = be.radius_edges(sources, targets, radius)
         enc[0] += g_lo
         enc[1] += h_lo
-        enc_counts_ready = comm.all_gather_sizes_async([enc.shape[1]], dev)  # read after the decoder is queued
-
-        # ---- decoder: my data band as targets, replicated hidden sources; only the source ids travel
-        # (the target row of a k-NN edge list is 0,0,0,1,1,1,... whatever the band)
-        ids = be.knn(hidden, self.data_local, self.k).reshape(-1)
-        band_sizes = [(self.bounds[i + 1] - self.bounds[i]) * self.k for i in range(W)]
-        dec_all = torch.empty((2, self.n_data * self.k), dtype=torch.int32, device=dev)
-        dec_gather = comm.all_gather_rows_async([ids], band_sizes, out=[dec_all[0]])
-        be.row_ids(self.n_data, self.k, dev, out=dec_all[1])
-
-        enc_counts = enc_counts_ready()[:, 0].tolist()
-        enc_all = torch.empty((2, sum(enc_counts)), dtype=enc.dtype, device=dev)
-        enc_gather = comm.all_gather_rows_async([enc[0], enc[1]], enc_counts, out=[enc_all[0], enc_all[1]])
+        enc_counts_ready = comm.all_gather_sizes_async([enc.shape[1]], dev)  # read once the processor is queued
 
         # ---- processor: replicated, while the edge lists travel
         proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,
@@ -319,16 +317,23 @@ class ShardedGraphBuilder:
         data_all = self.data_all
         graph["data"].x = data_all
         graph["data"].node_type = "LatLonNodes"
-        name = ("hidden", "to", "hidden")
-        graph[name].edge_index = proc
-        graph[name].edge_type = "MultiScaleEdges"
+        enc_name, proc_name, dec_name = ("data", "to", "hidden"), ("hidden", "to", "hidden"), ("hidden", "to", "data")
+        for name in (enc_name, proc_name, dec_name):  # edge sets in the order a single-GPU build registers them
+            graph[name]
+        graph[proc_name].edge_index = proc
+        graph[proc_name].edge_type = "MultiScaleEdges"
         if self.attributes:
-            self._finish_attrs(graph[name], *self._attrs(hidden, hidden, proc))
+            self._finish_attrs(graph[proc_name], *self._attrs(hidden, hidden, proc))
 
-        # ---- the complete edge lists; attributes on them (same kernels and inputs as a single-GPU build)
+        enc_counts = enc_counts_ready()[:, 0].tolist()
+        enc_all = torch.empty((2, sum(enc_counts)), dtype=enc.dtype, device=dev)
+        enc_gather = comm.all_gather_rows_async([enc[0], enc[1]], enc_counts, out=[enc_all[0], enc_all[1]])
+
+        # ---- the complete edge lists; attributes on them (same kernels and inputs as a single-GPU build);
+        # the decoder's ids left first, so its attributes are evaluated while the encoder's lists still travel
         for name, gather, edge_index, src_x, tgt_x, etype in (
-            (("data", "to", "hidden"), enc_gather, enc_all, data_all, hidden, "CutOffEdges"),
-            (("hidden", "to", "data"), dec_gather, dec_all, hidden, data_all, "KNNEdges"),
+            (dec_name, dec_gather, dec_all, hidden, data_all, "KNNEdges"),
+            (enc_name, enc_gather, enc_all, data_all, hidden, "CutOffEdges"),
         ):
             gather()
             graph[name].edge_index = edge_index
