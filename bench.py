@@ -245,7 +245,8 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 filter + f64 haversine ranking, int32 ids",
+        "dtype": "f64",
+        "dtype_note": "float64 haversine ranking behind a float32 filter, float32 attributes, int32 ids",
         "data": "synthetic",
         "config": {
             "workload": f"{grid_name.upper()} ({sizes['n_data']} nodes) -> icosphere r{resolution} "
