@@ -944,8 +944,10 @@ __global__ __launch_bounds__(256) void ag_radius_window_kernel(AgRadiusArgs a) {
     const float2 tpf = a.tgt[t];
     const float3 tu = ag_unit_vec(tpf.x, tpf.y);
     const double tlat = tpf.x, tlonw = ag_wrap_lon(static_cast<double>(tpf.y));
-    AgRadiusDesc d;
-    int run = 0, nruns = 1;
+    // the descriptor is written in place: only the runs that hold sources are kept (a band's second run
+    // is empty unless the longitude window wraps), so the search's run look-up is as short as the window
+    AgRadiusDesc* d = a.desc + t;
+    int run = 0, nruns = 1, kept = 0;
     bool merged = false;
     for (int j = 0; j < nruns; ++j) {
       int first, last;
@@ -954,26 +956,29 @@ __global__ __launch_bounds__(256) void ag_radius_window_kernel(AgRadiusArgs a) {
         merged = true;
         break;
       }
-      run += last - first;
-      d.first[j] = first;
-      d.incl[j] = run;
+      if (last > first) {
+        run += last - first;
+        d->first[kept] = first;
+        d->incl[kept] = run;
+        ++kept;
+      }
     }
     if (merged) {
       // more runs than the descriptor holds: one run over all covered bands (their cells are
       // contiguous in the binned array) -- a superset of the window
       const double pad = 1.0e-7 + 1.0e-6 * a.radius;
       const int b0 = ag_band_of(a.grid, tlat + a.radius + pad), b1 = ag_band_of(a.grid, tlat - a.radius - pad);
-      d.first[0] = a.sstart[a.grid.off[b0]];
-      run = a.sstart[a.grid.off[b1 + 1]] - d.first[0];
-      d.incl[0] = run;
-      nruns = 1;
+      const int first = a.sstart[a.grid.off[b0]];
+      run = a.sstart[a.grid.off[b1 + 1]] - first;
+      d->first[0] = first;
+      d->incl[0] = run;
+      kept = 1;
     }
-    for (int j = nruns; j < AG_RADIUS_RUNS; ++j) {
-      d.first[j] = 0;
-      d.incl[j] = run;
+    for (int j = kept; j < AG_RADIUS_RUNS; ++j) {
+      d->first[j] = 0;
+      d->incl[j] = run;
     }
-    d.unit = make_float4(tu.x, tu.y, tu.z, 0.0f);
-    a.desc[t] = d;
+    d->unit = make_float4(tu.x, tu.y, tu.z, __int_as_float(kept));  // (.w: the number of runs kept)
   }
 }
 
@@ -993,6 +998,7 @@ __device__ __forceinline__ int ag_radius_scan(const AgRadiusArgs& a, int64_t t, 
   const int4 fa = *reinterpret_cast<const int4*>(&d->first[0]), fb = *reinterpret_cast<const int4*>(&d->first[4]);
   const int4 ia = *reinterpret_cast<const int4*>(&d->incl[0]), ib = *reinterpret_cast<const int4*>(&d->incl[4]);
   const float4 tu = d->unit;
+  const int nkept = __builtin_amdgcn_readfirstlane(__float_as_int(tu.w));
   const int total = ib.w;
   int cnt = 0;
   for (int q0 = 0; q0 < total; q0 += 128) {
@@ -1004,14 +1010,23 @@ __device__ __forceinline__ int ag_radius_scan(const AgRadiusArgs& a, int64_t t, 
     for (int u = 0; u < 2; ++u) {
       q[u] = q0 + 64 * u + lane;
       live[u] = q[u] < total;
+      // run of candidate q: only as many steps as the window has runs (wave-uniform branches)
       int first = fa.x, excl = 0;
-      if (q[u] >= ia.x) { first = fa.y; excl = ia.x; }
-      if (q[u] >= ia.y) { first = fa.z; excl = ia.y; }
-      if (q[u] >= ia.z) { first = fa.w; excl = ia.z; }
-      if (q[u] >= ia.w) { first = fb.x; excl = ia.w; }
-      if (q[u] >= ib.x) { first = fb.y; excl = ib.x; }
-      if (q[u] >= ib.y) { first = fb.z; excl = ib.y; }
-      if (q[u] >= ib.z) { first = fb.w; excl = ib.z; }
+      if (nkept > 1) {
+        if (q[u] >= ia.x) { first = fa.y; excl = ia.x; }
+        if (nkept > 2) {
+          if (q[u] >= ia.y) { first = fa.z; excl = ia.y; }
+          if (nkept > 3) {
+            if (q[u] >= ia.z) { first = fa.w; excl = ia.z; }
+            if (nkept > 4) {
+              if (q[u] >= ia.w) { first = fb.x; excl = ia.w; }
+              if (q[u] >= ib.x) { first = fb.y; excl = ib.x; }
+              if (q[u] >= ib.y) { first = fb.z; excl = ib.y; }
+              if (q[u] >= ib.z) { first = fb.w; excl = ib.z; }
+            }
+          }
+        }
+      }
       s[u] = live[u] ? a.spts[first + (q[u] - excl)] : make_float4(4.f, 4.f, 4.f, 0.f);
     }
 #pragma unroll

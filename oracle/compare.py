@@ -32,9 +32,19 @@ def knn_rows(edge_index: np.ndarray, nt: int, k: int) -> np.ndarray:
     return e[0].reshape(nt, k)
 
 
-def compare_knn(src, tgt, ids_a: np.ndarray, ids_b: np.ndarray) -> dict:
+# With at most 11 sources scikit-learn answers by brute force (sklearn/neighbors/_base.py:622-655: n_neighbors
+# >= n_samples // 2 with the default n_neighbors = 5) and evaluates the haversine metric on the float32 inputs
+# in float32: its ranking is only float32-accurate there, so members that differ by less than this count as tied.
+BRUTE_MAX_SOURCES = 11
+BRUTE_TIE_RTOL = 2e-6
+
+
+def compare_knn(src, tgt, ids_a: np.ndarray, ids_b: np.ndarray, tie_rtol: float | None = None) -> dict:
     """Row-wise set comparison of two [nt,k] neighbour tables.  Rows whose sets differ must differ
-    only in members whose float64 rdist ties with the k-th smallest (within TIE_RTOL)."""
+    only in members whose float64 rdist ties with the k-th smallest (within TIE_RTOL; BRUTE_TIE_RTOL
+    for source sets small enough for the reference's float32 brute-force path)."""
+    if tie_rtol is None:
+        tie_rtol = BRUTE_TIE_RTOL if len(src) <= BRUTE_MAX_SOURCES else TIE_RTOL
     nt, k = ids_a.shape
     sa, sb = np.sort(ids_a, axis=1), np.sort(ids_b, axis=1)
     diff_rows = np.where((sa != sb).any(axis=1))[0]
@@ -45,7 +55,7 @@ def compare_knn(src, tgt, ids_a: np.ndarray, ids_b: np.ndarray) -> dict:
         kth = ra.max()
         odd = np.array(sorted(a ^ b))
         ro = rdist64(tgt[t][None, :], src[odd])
-        if not np.all(np.abs(ro - kth) <= TIE_RTOL * max(kth, 1e-300)):
+        if not np.all(np.abs(ro - kth) <= tie_rtol * max(kth, 1e-300)):
             bad.append(int(t))
     return {"rows": nt, "tie_rows": int(len(diff_rows) - len(bad)), "bad_rows": bad}
 
