@@ -1,4 +1,4 @@
-"""GPU, two or three processes sharing the one GPU over gloo (tensors staged through host memory), and one
+"""GPU, two, three or eight processes sharing the one GPU over gloo (tensors staged through host memory), and one
 process over RCCL with device tensors: the latitude-band sharded build with the HIP kernels yields exactly the
 single-process graph."""
 import os
@@ -57,6 +57,7 @@ def _worker(rank, world, port, grid, resolution, factor, out_dir, backend="gloo"
 
 @pytest.mark.parametrize("grid,resolution,factor,world,backend", [
     ("o96", 4, 0.6, 2, "gloo"), ("o320", 5, 0.6, 3, "gloo"), ("o96", 3, 3.0, 2, "gloo"),
+    ("o320", 5, 0.6, 8, "gloo"),  # as many ranks as a node has GPUs
     # RCCL with device tensors: one rank only, two ranks cannot share the one GPU of the test machine
     ("o320", 5, 0.6, 1, "nccl"),
 ])
