@@ -347,6 +347,7 @@ struct AgBinned {
   int64_t ncells_ub = 0;        // host-side upper bound of the number of cells
   const float4* pts = nullptr;  // [n]  (x, y, z, bits of original id) in binned order (optional)
   const int* ids = nullptr;     // [n]  original id of every binned position
+  const int* cell_of = nullptr; // [n]  cell of every point, by original id
   const int* cell_start = nullptr; // [ncells_ub + 1]
 };
 

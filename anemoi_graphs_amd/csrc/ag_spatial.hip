@@ -174,6 +174,7 @@ static void ag_bin_describe(const AgBinCarve& c, int64_t n, int nb, int mult, Ag
   out->ncells_ub = ag_grid_cells_ub(nb, mult);
   out->pts = c.pts;
   out->ids = c.ids;
+  out->cell_of = c.cell_of;
   out->cell_start = c.cell_start;
 }
 
@@ -227,7 +228,11 @@ struct AgKnnArgs {
   int* cand_ids;             // [CAP][nt] candidate ids by queue slot, coalesced per rank
   int* queue;                // [nt] targets left to stage 2
   int* queue_count;
-  const struct AgWindow* windows;  // [target cells] precomputed source runs
+  const struct AgWindow* windows;  // [nwin] one descriptor per wave of stage 1: its targets and their source runs
+  int nwin;                  // number of descriptors (an upper bound known to the host; unused ones are empty)
+  int by_range;              // 1: a descriptor is 64 consecutive binned targets of one band; 0: a target cell
+  const int* tcell_of;       // cell of every target, by original id
+  int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
   unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
   long long* stats;          // [4]
@@ -300,15 +305,50 @@ __device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __res
   }
 }
 
-// A window descriptor: up to AG_WIN_RANGES half-open runs of binned sources, 64 bytes.
-// d[0] = number of runs (-1: too many, enumerate inline), d[1 + 2i], d[2 + 2i] = run i.
+// The work of one wave of stage 1: the binned targets [t0, t1) -- all in latitude band `band`, with
+// longitudes inside [lon_lo, lon_hi] -- and up to AG_WIN_RANGES half-open runs of binned sources that
+// hold every source within the guaranteed radius of any of them.
+// d[0] = number of runs (-1: too many, the wave enumerates them itself), d[1 + 2i], d[2 + 2i] = run i.
 #define AG_WIN_RANGES 7
-struct __attribute__((aligned(64))) AgWindow {
+struct __attribute__((aligned(32))) AgWindow {
   int d[16];
+  int t0, t1, band, pad;
+  double lon_lo, lon_hi;
 };
 
-// one thread per target cell: the runs of sources that cover the cell (stage 1 then starts with
-// two independent loads instead of a chain of dependent table look-ups per wave)
+// Dense target sets: descriptors are ranges of 64 consecutive binned targets that never cross a band,
+// so every lane of a wave has a target whatever the cell populations are (a regular latitude-longitude
+// grid puts thousands of targets into a polar cell and a handful into its neighbours).  One block:
+// range_off[b] = number of ranges of the bands before b.
+__global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
+  __shared__ int partial[1024];
+  const int nb = a.tgrid.nb, tid = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int b_begin = tid * per, b_end = min(nb, b_begin + per);
+  int sum = 0;
+  for (int b = b_begin; b < b_end; ++b) {
+    const int cnt = a.tstart[a.tgrid.off[b + 1]] - a.tstart[a.tgrid.off[b]];
+    sum += (cnt + 63) >> 6;
+  }
+  partial[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (tid >= d) ? partial[tid - d] : 0;
+    __syncthreads();
+    partial[tid] += v;
+    __syncthreads();
+  }
+  int run = partial[tid] - sum;
+  for (int b = b_begin; b < b_end; ++b) {
+    a.range_off[b] = run;
+    const int cnt = a.tstart[a.tgrid.off[b + 1]] - a.tstart[a.tgrid.off[b]];
+    run += (cnt + 63) >> 6;
+  }
+  if (tid == 1023) a.range_off[nb] = partial[1023];
+}
+
+// one thread per descriptor: the targets of the wave and the runs of sources that cover them (stage 1
+// then starts with one load instead of a chain of dependent table look-ups per wave)
 __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the stages that follow
     a.queue_count[0] = 0;  // stage-2 queue
@@ -316,23 +356,57 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
     if (a.max_bits) *a.max_bits = 0ull;
     if (a.stats) a.stats[0] = a.stats[1] = a.stats[2] = a.stats[3] = 0;
   }
-  const int ncells = a.tgrid.off[a.tgrid.nb];
-  for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += gridDim.x * blockDim.x) {
-    if (a.tstart[cell] >= a.tstart[cell + 1]) continue;
-    const int band = ag_band_of_cell(a.tgrid, cell);
-    const int col = cell - a.tgrid.off[band];
-    const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
+  const int nb = a.tgrid.nb;
+  const int used = a.by_range ? a.range_off[nb] : a.tgrid.off[nb];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.nwin; i += gridDim.x * blockDim.x) {
     AgWindow w;
-    int n = 0;
-    ag_cell_window(a.sgrid, a.sstart, band, col * wlon, (col + 1) * wlon, [&](int first, int last) {
-      if (first < last && n < AG_WIN_RANGES) {
-        w.d[1 + 2 * n] = first;
-        w.d[2 + 2 * n] = last;
+    w.t0 = w.t1 = 0;
+    w.band = 0;
+    w.pad = 0;
+    w.lon_lo = w.lon_hi = 0.0;
+    w.d[0] = 0;
+    int band = 0, col_first = 0, col_last = 0;
+    if (i < used) {
+      if (a.by_range) {
+        int lo = 0, hi = nb - 1;  // last band whose first range is <= i (bands without targets share an offset)
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (a.range_off[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        band = lo;
+        const int b0 = a.tstart[a.tgrid.off[band]], b1 = a.tstart[a.tgrid.off[band + 1]];
+        w.t0 = b0 + 64 * (i - a.range_off[band]);
+        w.t1 = min(w.t0 + 64, b1);
+        // binned targets are ordered by cell, so the cells of the first and the last target bound the rest
+        col_first = a.tcell_of[a.tids[w.t0]] - a.tgrid.off[band];
+        col_last = a.tcell_of[a.tids[w.t1 - 1]] - a.tgrid.off[band];
+      } else {
+        w.t0 = a.tstart[i];
+        w.t1 = a.tstart[i + 1];
+        if (w.t0 < w.t1) {
+          band = ag_band_of_cell(a.tgrid, i);
+          col_first = col_last = i - a.tgrid.off[band];
+        }
       }
-      if (first < last) ++n;
-    });
-    w.d[0] = n <= AG_WIN_RANGES ? n : -1;
-    out[cell] = w;
+    }
+    if (w.t0 < w.t1) {
+      const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
+      w.band = band;
+      w.lon_lo = col_first * wlon;
+      w.lon_hi = (col_last + 1) * wlon;
+      int n = 0;
+      ag_cell_window(a.sgrid, a.sstart, band, w.lon_lo, w.lon_hi, [&](int first, int last) {
+        if (first < last && n < AG_WIN_RANGES) {
+          w.d[1 + 2 * n] = first;
+          w.d[2 + 2 * n] = last;
+        }
+        if (first < last) ++n;
+      });
+      w.d[0] = n <= AG_WIN_RANGES ? n : -1;
+    } else {
+      w.t0 = w.t1 = 0;
+    }
+    out[i] = w;
   }
 }
 
@@ -342,12 +416,11 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = ag_lane();
   float4* tile = tile_all[wave];
-  const int ncells = a.tgrid.off[a.tgrid.nb];
-  const int cell = __builtin_amdgcn_readfirstlane(blockIdx.x * AG_WAVES_PER_BLOCK + wave);
-  if (cell >= ncells) return;
-  const int t0 = a.tstart[cell], t1 = a.tstart[cell + 1];
+  const int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * AG_WAVES_PER_BLOCK + wave);
+  if (wi >= a.nwin) return;
+  const AgWindow win = a.windows[wi];
+  const int t0 = win.t0, t1 = win.t1;
   if (t0 >= t1) return;
-  const AgWindow win = a.windows[cell];
   const int k = a.k;
 
   for (int tb = t0; tb < t1; tb += 64) {
@@ -454,10 +527,7 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       for (int r = 0; r < AG_WIN_RANGES; ++r)
         if (r < win.d[0]) stage_run(win.d[1 + 2 * r], win.d[2 + 2 * r]);
     } else {
-      const int band = ag_band_of_cell(a.tgrid, cell);
-      const int col = cell - a.tgrid.off[band];
-      const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
-      ag_cell_window(a.sgrid, a.sstart, band, col * wlon, (col + 1) * wlon, stage_run);
+      ag_cell_window(a.sgrid, a.sstart, win.band, win.lon_lo, win.lon_hi, stage_run);
     }
     if (fill > 0) scan_tile(fill);
 
@@ -742,9 +812,18 @@ static int ag_knn_tmult(int64_t nt, int nb) {
   return m;
 }
 
+// Dense target sets (what ag_knn_tmult answers with a multiplier >= 1) take their stage-1 descriptors by
+// ranges of 64 binned targets; sparse ones by (merged) target cells.
+static bool ag_knn_by_range(int tmult) { return tmult >= 1; }
+// descriptors of a search: one per target cell, or one per range (every band ends with a partial one)
+static int64_t ag_knn_windows_ub(int64_t nt, int nb, int tmult) {
+  return ag_knn_by_range(tmult) ? (nt + 63) / 64 + nb : ag_grid_cells_ub(nb, tmult);
+}
+
 struct AgKnnWs {
   AgBinned src, tgt;
   int tmult;
+  int* range_off;
   int* queue;
   int* queue_count;
   unsigned long long* max_bits;
@@ -769,9 +848,11 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* cand_n = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
   int* cand_t = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
   int* cand_ids = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt * cap) : nullptr;
-  AgWindow* windows = c.take<AgWindow>(ag_grid_cells_ub(nb, tmult) + 1);
+  AgWindow* windows = c.take<AgWindow>(ag_knn_windows_ub(nt, nb, tmult) + 1);
+  int* range_off = c.take<int>(nb + 1);
   if (w) {
     w->windows = windows;
+    w->range_off = range_off;
     w->tmult = tmult;
     w->queue = queue;
     w->queue_count = queue_count;
@@ -784,8 +865,8 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
 }
 
 template <int CAP>
-static void ag_launch_stage1(const AgKnnArgs& a, int64_t tcells_ub, hipStream_t stream) {
-  const int blocks = ag_blocks(tcells_ub, AG_WAVES_PER_BLOCK);
+static void ag_launch_stage1(const AgKnnArgs& a, hipStream_t stream) {
+  const int blocks = ag_blocks(a.nwin, AG_WAVES_PER_BLOCK);
   AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
   if constexpr (CAP <= AG_KNN_RESOLVE_CAP) {
     AG_KERNEL("ag_knn_resolve_kernel", ag_knn_resolve_kernel<CAP>, dim3(ag_blocks(a.nt, 256, 8192)), dim3(256), stream, a);
@@ -827,22 +908,29 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.queue = w.queue;
   a.queue_count = w.queue_count;
   a.windows = w.windows;
+  a.by_range = ag_knn_by_range(w.tmult) ? 1 : 0;
+  a.nwin = static_cast<int>(ag_knn_windows_ub(nt, w.tgt.grid.nb, w.tmult));
+  a.tcell_of = w.tgt.cell_of;
+  a.range_off = w.range_off;
   a.self_query = self_query ? 1 : 0;
   a.max_bits = w.max_bits;
   a.stats = reinterpret_cast<long long*>(d_stats);
 
-  const int64_t tcu = w.tgt.ncells_ub;
-  AG_KERNEL("ag_knn_window_kernel", ag_knn_window_kernel, dim3(ag_blocks(tcu, 256, 8192)), dim3(256), stream, a,
+  if (a.by_range) {
+    AG_KERNEL("ag_knn_band_ranges_kernel", ag_knn_band_ranges_kernel, dim3(1), dim3(1024), stream, a);
+    AG_LAUNCH_CHECK();
+  }
+  AG_KERNEL("ag_knn_window_kernel", ag_knn_window_kernel, dim3(ag_blocks(a.nwin, 256, 8192)), dim3(256), stream, a,
             w.windows);
   AG_LAUNCH_CHECK();
   switch (ag_knn_cap(k, self_query)) {
-    case 3: ag_launch_stage1<3>(a, tcu, stream); break;
-    case 5: ag_launch_stage1<5>(a, tcu, stream); break;
-    case 8: ag_launch_stage1<8>(a, tcu, stream); break;
-    case 12: ag_launch_stage1<12>(a, tcu, stream); break;
-    case 18: ag_launch_stage1<18>(a, tcu, stream); break;
-    case 34: ag_launch_stage1<34>(a, tcu, stream); break;
-    default: ag_launch_stage1<AG_KNN_MAX_K + 2>(a, tcu, stream); break;
+    case 3: ag_launch_stage1<3>(a, stream); break;
+    case 5: ag_launch_stage1<5>(a, stream); break;
+    case 8: ag_launch_stage1<8>(a, stream); break;
+    case 12: ag_launch_stage1<12>(a, stream); break;
+    case 18: ag_launch_stage1<18>(a, stream); break;
+    case 34: ag_launch_stage1<34>(a, stream); break;
+    default: ag_launch_stage1<AG_KNN_MAX_K + 2>(a, stream); break;
   }
   AG_LAUNCH_CHECK();
   AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
