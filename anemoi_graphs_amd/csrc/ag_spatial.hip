@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(256) void ag_radius_count_kernel(AgRadiusArgs a) {
   }
 }
 
-#define AG_COPY_GROUP 64  // targets per block of the copy kernel
+#define AG_COPY_GROUP 16  // targets per block of the copy kernel
 
 // Fill pass, rows kept by the count pass: a block copies the rows of AG_COPY_GROUP consecutive
 // targets; its threads stride over the block's contiguous piece of the output and find their row
