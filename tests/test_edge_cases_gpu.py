@@ -108,3 +108,27 @@ def test_mask_all_false_and_all_true(device):
     m0 = ops.mask_ids(torch.zeros(100, dtype=torch.bool), device)
     m1 = ops.mask_ids(torch.ones(100, dtype=torch.bool), device)
     assert m0.numel() == 0 and np.array_equal(m1.cpu().numpy(), np.arange(100))
+
+
+@pytest.mark.parametrize("case", ["latlon_grid_with_poles", "one_band_multiple_of_64", "one_band_plus_one", "two_caps"])
+def test_dense_targets_by_ranges(device, case):
+    """Dense target sets are searched in ranges of 64 binned targets per latitude band: bands whose
+    population is an exact multiple of 64, one more than that, thousands of coincident targets at a
+    pole, and bands without any target between populated ones."""
+    rng = np.random.default_rng(17)
+    src = grids.fibonacci_sphere(500)
+    if case == "latlon_grid_with_poles":
+        tgt = grids.regular(1.0)  # 181 x 360, the two pole rows are 360 coincident points each
+    elif case == "one_band_multiple_of_64":
+        tgt = np.stack([np.full(64 * 300, 0.4), rng.uniform(0, 2 * np.pi, 64 * 300)], axis=1)
+    elif case == "one_band_plus_one":
+        tgt = np.stack([0.4 + rng.uniform(-1e-3, 1e-3, 64 * 300 + 1), rng.uniform(0, 2 * np.pi, 64 * 300 + 1)], axis=1)
+    else:
+        lat = np.concatenate([np.pi / 2 - np.abs(rng.normal(0, 0.05, 15000)), -np.pi / 2 + np.abs(rng.normal(0, 0.05, 15000))])
+        tgt = np.stack([lat, rng.uniform(-np.pi, np.pi, 30000)], axis=1)
+    tgt = tgt.astype(np.float32)
+    for k in (1, 3, 7):
+        got = ops.knn(_t(src, device), _t(tgt, device), k).cpu().numpy()
+        want = h.knn_rows(rp.knn_edges(src, tgt, k), len(tgt), k)
+        res = h.compare_knn(src, tgt, got, want)
+        assert res["bad_rows"] == [], (case, k, res)
