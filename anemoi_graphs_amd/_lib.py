@@ -37,6 +37,9 @@ SIGNATURES = {
         c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "ag_multiscale_fill": (
         c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "ag_multiscale_complete_edges": (c_int64, [ctypes.POINTER(ctypes.c_int32), c_int]),
+    "ag_multiscale_complete": (
+        c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "ag_edge_attrs": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P]),
     "ag_edge_attrs_range": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ag_len_range_words": (c_size_t, []),

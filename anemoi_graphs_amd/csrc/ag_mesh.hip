@@ -619,6 +619,89 @@ __global__ void ag_ms_edge_pairs_kernel(const uint64_t* __restrict__ level_edges
   }
 }
 
+// x_hops == 1 on the COMPLETE icosphere (no vertex mask): the rows need no counting pass.  A vertex v exists
+// from its birth level on (the first level with more than v vertices) and has 5 neighbours on every level if it
+// is one of the 12 icosahedron vertices, else 6, so its row holds deg(v) entries per selected level it exists on.
+// Also clears the per-row counters of the placement pass and the state of the scan that follows.
+__global__ void ag_ms_row_sizes_kernel(int64_t V, unsigned level_mask, int R, const int32_t* __restrict__ rank,
+                                       int* __restrict__ row_count, int2* __restrict__ placed,
+                                       unsigned long long* __restrict__ scan_state, int64_t scan_words) {
+  const int64_t i0 = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, step = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t v = i0; v < V; v += step) {
+    int levels_alive = 0;
+    for (int l = 0; l <= R; ++l)
+      if (((level_mask >> l) & 1u) && (10ll << (2 * l)) + 2 > v) ++levels_alive;
+    const int r = rank[v];
+    if (r >= 0 && r < V) row_count[r] = (v < 12 ? 5 : 6) * levels_alive;
+    placed[v] = make_int2(0, 0);
+  }
+  if (i0 == 0) row_count[V] = row_count[V + 1] = 0;
+  for (int64_t i = i0; i < scan_words; i += step) scan_state[i] = 0ull;
+}
+
+// Placement on the complete icosphere, one thread per mesh edge (min, max) of the selected levels; every edge
+// puts `min` into the row of `max` and `max` into the row of `min`.
+//  * A vertex has smaller neighbours on its birth level only (from the next level on all its neighbours are
+//    midpoints created later), so the entries `min` of a row form one block, kept at the front of the row; the
+//    entries `max` are taken from the back of the row with one atomic counter per row.  The rows are ordered by
+//    the pass that follows, so the order inside the two blocks is free.
+//  * Front slots mostly need no counter.  The edges of every level but the mesh's finest are ordered by
+//    (max, min): the slot is the number of edges with the same `max` right before this one.  The finest level R is
+//    stored as ag_icosphere leaves it -- for every edge i of level R-1 with midpoint m = V(R-1) + i the pair
+//    (a, m), (b, m) at 2i and 2i+1, then the three sides of every central child face: the pair takes slots 0 and
+//    1 of the row of m, the sides take the slots from 2 on with a second counter.
+__global__ void ag_ms_place_kernel(const uint64_t* __restrict__ level_edges, AgMsLevels lv, int final_index,
+                                   int64_t final_split, const int32_t* __restrict__ rank,
+                                   const int* __restrict__ row_start, int64_t V, int64_t E, int2* __restrict__ placed,
+                                   int32_t* __restrict__ out_src, int32_t* __restrict__ out_tgt) {
+  const int64_t total = lv.end[lv.n - 1];
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    int64_t start = 0, eoff = lv.edge_off[0];
+    int which = 0;
+#pragma unroll
+    for (int j = 1; j < AG_MS_MAX_LEVELS; ++j) {
+      if (i >= lv.end[j - 1]) {
+        start = lv.end[j - 1];
+        eoff = lv.edge_off[j];
+        which = j;
+      }
+    }
+    const int64_t local = i - start;
+    const uint64_t* edges = level_edges + eoff;
+    const uint64_t k = edges[local];
+    const int vmin = static_cast<int>(static_cast<uint32_t>(k)), vmax = static_cast<int>(static_cast<uint32_t>(k >> 32));
+    if (vmin < 0 || vmax >= V || vmin >= vmax) continue;  // not an edge of this mesh
+    const int rmin = rank[vmin], rmax = rank[vmax];
+    if (rmin < 0 || rmin >= V || rmax < 0 || rmax >= V) continue;  // not a complete mesh: nothing is placed
+    int front_slot;
+    if (which != final_index) {
+      int before = 0;
+      bool same = true;
+#pragma unroll
+      for (int d = 1; d < AG_MAX_DEG; ++d) {
+        const int64_t q = local - d;
+        same = same && q >= 0 && static_cast<int>(static_cast<uint32_t>(edges[q >= 0 ? q : 0] >> 32)) == vmax;
+        before += same ? 1 : 0;
+      }
+      front_slot = before;
+    } else if (local < final_split) {
+      front_slot = static_cast<int>(local & 1);
+    } else {
+      front_slot = 2 + atomicAdd(&placed[vmax].x, 1);
+    }
+    const int front = row_start[rmax] + front_slot;
+    if (front >= 0 && front < row_start[rmax + 1] && front < E) {
+      out_src[front] = rmin;
+      out_tgt[front] = rmax;
+    }
+    const int back = row_start[rmin + 1] - 1 - atomicAdd(&placed[vmin].y, 1);
+    if (back >= 0 && back >= row_start[rmin] && back < E) {
+      out_src[back] = rmax;
+      out_tgt[back] = rmin;
+    }
+  }
+}
+
 __global__ void ag_ms_scatter_kernel(const uint64_t* __restrict__ pairs, const int* __restrict__ slot, int64_t n, int B,
                                      const int* __restrict__ row_start, int32_t* __restrict__ out_src,
                                      int32_t* __restrict__ out_tgt) {
@@ -636,10 +719,13 @@ __global__ void ag_ms_scatter_kernel(const uint64_t* __restrict__ pairs, const i
 // the position of an entry is the number of smaller entries of its row (rows are short: at most
 // 6 per level).
 __global__ void ag_ms_row_rank_kernel(const int* __restrict__ row_start, const int32_t* __restrict__ unsorted,
-                                      const int32_t* __restrict__ out_tgt, int64_t E, int32_t* __restrict__ out_src) {
+                                      const int32_t* __restrict__ out_tgt, int64_t E, int64_t V,
+                                      int32_t* __restrict__ out_src) {
   for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < E; e += int64_t(gridDim.x) * blockDim.x) {
     const int t = out_tgt[e];
+    if (t < 0 || t >= V) continue;  // (an entry nothing was placed into)
     const int first = row_start[t], n = row_start[t + 1] - first;
+    if (first < 0 || n < 0 || int64_t(first) + n > E) continue;  // (row offsets of an inconsistent input)
     const int32_t mine = unsorted[e];
     int r = 0;
     for (int j = 0; j < n; ++j) r += (unsorted[first + j] < mine) ? 1 : 0;
@@ -745,6 +831,7 @@ struct AgMsWs {
   int64_t row_clear;  // ints to clear from row_start on: the counters and the scan state behind them
   unsigned long long* row_scan_state;
   int32_t* unsorted;  // [total slots]  sources grouped by target, unsorted inside a row (x_hops == 1)
+  int2* placed;       // [V_R]          entries placed at the front / from the back of a row (complete icosphere)
   void* temp;
   size_t temp_bytes;
   int64_t slots;
@@ -776,6 +863,7 @@ static int ag_ms_carve(AgCarver& c, int R, const int32_t* levels, int nlevels, i
   m.row_clear = row_ints + 2 * scan_words;
   m.row_scan_state = x_hops == 1 ? reinterpret_cast<unsigned long long*>(m.row_start + row_ints) : nullptr;
   m.unsorted = x_hops == 1 ? c.take<int32_t>(slots) : nullptr;
+  m.placed = x_hops == 1 ? c.take<int2>(ag_ico_V(R)) : nullptr;
   size_t t1 = ag_sort_u64_temp_bytes(slots), t2 = ag_scan_i64_temp_bytes(slots);
   if (x_hops == 1) {
     t1 = ag_scan_i32_temp_bytes(ag_ico_V(R) + 2);
@@ -894,17 +982,70 @@ extern "C" int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int
   if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_fill: workspace too small");
   if (x_hops == 1) {
     const int64_t V = ag_ico_V(R);
-    (void)V;
     AG_KERNEL("ag_ms_scatter_kernel", ag_ms_scatter_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_a,
               m.slot, m.slots, ag_vertex_bits(R), m.row_start, m.unsorted, d_out_tgt);
     AG_LAUNCH_CHECK();
     AG_KERNEL("ag_ms_row_rank_kernel", ag_ms_row_rank_kernel, dim3(ag_blocks(num_edges, 256, 8192)), dim3(256), s,
-              m.row_start, m.unsorted, d_out_tgt, num_edges, d_out_src);
+              m.row_start, m.unsorted, d_out_tgt, num_edges, V, d_out_src);
     AG_LAUNCH_CHECK();
     return AG_OK;
   }
   AG_KERNEL("ag_ms_emit_kernel", ag_ms_emit_kernel, dim3(ag_blocks(m.slots, 256, 8192)), dim3(256), s, m.pairs_b,
             m.offsets, m.slots, ag_vertex_bits(R), num_edges, d_out_src, d_out_tgt);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+// number of multi-scale edges of the complete icosphere for x_hops == 1: level l has 30 * 4^l mesh edges, each
+// listed in both directions, and no pair occurs on two levels (an edge of one level is split on the next)
+extern "C" int64_t ag_multiscale_complete_edges(const int32_t* levels, int nlevels) {
+  int64_t n = 0;
+  for (int i = 0; levels != nullptr && i < nlevels; ++i)
+    if (levels[i] >= 0 && levels[i] <= AG_ICO_MAX_LEVEL) n += 2 * ag_ico_E(levels[i]);
+  return n;
+}
+
+extern "C" int ag_multiscale_complete(int R, const int32_t* levels, int nlevels, const int32_t* d_rank,
+                                      const uint64_t* d_level_edges, int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws,
+                                      size_t ws_bytes, void* stream) {
+  int rc = ag_ms_check(R, levels, nlevels, 1);
+  if (rc) return rc;
+  AG_REQUIRE(d_rank && d_level_edges && d_out_src && d_out_tgt && d_ws, "ag_multiscale_complete: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AgCarver c(d_ws);
+  AgMsWs m;
+  ag_ms_carve(c, R, levels, nlevels, 1, &m);
+  if (ws_bytes < c.total()) return ag_fail(AG_ERR_WORKSPACE, "ag_multiscale_complete: workspace too small");
+  AgMsLevels lv;
+  lv.n = nlevels;
+  int64_t run = 0;
+  unsigned level_mask = 0u;
+  int final_index = -1;  // position in the level list of the mesh's finest level, whose edges are stored unsorted
+  for (int i = 0; i < nlevels; ++i) {
+    lv.edge_off[i] = ag_ico_edge_offset(levels[i]);
+    run += ag_ico_E(levels[i]);
+    lv.end[i] = run;
+    level_mask |= 1u << levels[i];
+    if (levels[i] == R && R > 0) final_index = i;
+  }
+  const int64_t final_split = R > 0 ? 2 * ag_ico_E(R - 1) : 0;
+  for (int i = nlevels; i < AG_MS_MAX_LEVELS; ++i) {
+    lv.edge_off[i] = 0;
+    lv.end[i] = run;
+  }
+  const int64_t V = ag_ico_V(R), num_edges = 2 * run;
+  AG_REQUIRE(num_edges < (int64_t(1) << 31), "ag_multiscale_complete: too many edges for 32-bit row offsets");
+  const int64_t scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i32(V + 2));
+  AG_KERNEL("ag_ms_row_sizes_kernel", ag_ms_row_sizes_kernel, dim3(ag_blocks(V, 256, 8192)), dim3(256), s, V, level_mask,
+            R, d_rank, m.row_start, m.placed, m.row_scan_state, scan_words);
+  AG_LAUNCH_CHECK();
+  rc = ag_chained_scan_i32(m.row_start, m.row_start, V, m.row_scan_state, s, nullptr);
+  if (rc) return rc;
+  AG_KERNEL("ag_ms_place_kernel", ag_ms_place_kernel, dim3(ag_blocks(run, 256, 8192)), dim3(256), s, d_level_edges, lv,
+            final_index, final_split, d_rank, m.row_start, V, num_edges, m.placed, m.unsorted, d_out_tgt);
+  AG_LAUNCH_CHECK();
+  AG_KERNEL("ag_ms_row_rank_kernel", ag_ms_row_rank_kernel, dim3(ag_blocks(num_edges, 256, 8192)), dim3(256), s,
+            m.row_start, m.unsorted, d_out_tgt, num_edges, V, d_out_src);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -281,6 +281,19 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
     lv = (ctypes.c_int32 * len(levels))(*[int(v) for v in levels])
     act = None if active is None else active.to(device=dev, dtype=torch.uint8).contiguous()
     with torch.cuda.device(dev):
+        if act is None and x_hops == 1 and len(set(int(v) for v in levels)) == len(levels):
+            # The complete icosphere: the edge count is a closed form (level l has 30 * 4^l mesh edges, each listed
+            # in both directions, and edges of different levels never coincide), so nothing is asked of the device
+            # before the output is allocated, and one call builds the rows without a counting pass.
+            num_edges = int(lib.ag_multiscale_complete_edges(lv, len(levels)))
+            edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
+            ws = _workspace(lib.ag_multiscale_workspace_bytes(max_resolution, len(levels), 1), dev)
+            _lib.check(
+                lib.ag_multiscale_complete(max_resolution, lv, len(levels), _ptr(rank), _ptr(level_edges),
+                                           _ptr(edge_index[0]), _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_multiscale_complete",
+            )
+            return edge_index
         count = torch.zeros((), dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_multiscale_workspace_bytes(max_resolution, len(levels), x_hops), dev)
         _lib.check(
@@ -288,13 +301,7 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
                                     _ptr(count), _ptr(ws), ws.numel(), _stream(dev)),
             "ag_multiscale_count",
         )
-        if act is None and x_hops == 1 and len(set(int(v) for v in levels)) == len(levels):
-            # The complete icosphere needs no answer from the device: level l has 30 * 4^l undirected
-            # edges, each listed in both directions, and edges of different levels never coincide (a
-            # level's edge is split by a midpoint on the next), so the host does not wait here.
-            num_edges = sum(60 * 4 ** int(v) for v in levels)
-        else:
-            num_edges = int(count.item())
+        num_edges = int(count.item())
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
         if num_edges:
             _lib.check(

@@ -139,6 +139,16 @@ int ag_multiscale_count(int R, const int32_t* levels, int nlevels, int x_hops, c
 int ag_multiscale_fill(int R, const int32_t* levels, int nlevels, int x_hops, int64_t num_edges, int32_t* d_out_src,
                        int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream);
 
+/* The same edges for x_hops = 1 on the COMPLETE icosphere (every vertex a node: d_rank a permutation, no
+ * mask) -- what MultiScaleEdges builds on TriNodes (edges/builder.py:412-420) -- in one call and without
+ * a host round trip: the edge count is a closed form, ag_multiscale_complete_edges(levels, nlevels) =
+ * sum of 60 * 4^l (docs/graphs/edges/tri_refined_edges.csv), which sizes d_out_src / d_out_tgt.
+ * Workspace: ag_multiscale_workspace_bytes(R, nlevels, 1). */
+int64_t ag_multiscale_complete_edges(const int32_t* levels, int nlevels);
+int ag_multiscale_complete(int R, const int32_t* levels, int nlevels, const int32_t* d_rank,
+                           const uint64_t* d_level_edges, int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws,
+                           size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Edge attributes.
  * Replaces EdgeLength.get_raw_values -> utils.haversine_distance (edges/attributes.py:144-148,
