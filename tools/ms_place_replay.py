@@ -76,5 +76,9 @@ def emulate(R, levels):
     assert got == want and len(want) == len(out_src)
     return len(out_src)
 
-for R, levels in [(0, [0]), (1, [0, 1]), (1, [1]), (2, [0, 1, 2]), (2, [0, 2]), (3, [0, 1, 2, 3]), (3, [1, 3]), (3, [2]), (4, [0,1,2,3,4]), (4, [4]), (4,[0,3])]:
-    print(R, levels, emulate(R, levels))
+CASES = [(0, [0]), (1, [0, 1]), (1, [1]), (2, [0, 1, 2]), (2, [0, 2]), (3, [0, 1, 2, 3]), (3, [1, 3]), (3, [2]),
+         (4, [0, 1, 2, 3, 4]), (4, [4]), (4, [0, 3])]
+
+if __name__ == "__main__":
+    for R, levels in CASES:
+        print(R, levels, emulate(R, levels))
