@@ -230,7 +230,8 @@ struct AgKnnArgs {
   int* queue_count;
   const struct AgWindow* windows;  // [nwin] one descriptor per wave of stage 1: its targets and their source runs
   int nwin;                  // number of descriptors (an upper bound known to the host; unused ones are empty)
-  int by_range;              // 1: a descriptor is 64 consecutive binned targets of one band; 0: a target cell
+  int by_range;              // 1: a descriptor is `range_len` consecutive binned targets of one band; 0: a target cell
+  int range_len;             // 64 for dense target sets; fewer for a set queried against itself (sparse: the window grows with the span)
   const int* tcell_of;       // cell of every target, by original id
   int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
   int sum = 0;
   for (int b = b_begin; b < b_end; ++b) {
     const int cnt = a.tstart[a.tgrid.off[b + 1]] - a.tstart[a.tgrid.off[b]];
-    sum += (cnt + 63) >> 6;
+    sum += (cnt + a.range_len - 1) / a.range_len;
   }
   partial[tid] = sum;
   __syncthreads();
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
   for (int b = b_begin; b < b_end; ++b) {
     a.range_off[b] = run;
     const int cnt = a.tstart[a.tgrid.off[b + 1]] - a.tstart[a.tgrid.off[b]];
-    run += (cnt + 63) >> 6;
+    run += (cnt + a.range_len - 1) / a.range_len;
   }
   if (tid == 1023) a.range_off[nb] = partial[1023];
 }
@@ -375,8 +376,8 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
         }
         band = lo;
         const int b0 = a.tstart[a.tgrid.off[band]], b1 = a.tstart[a.tgrid.off[band + 1]];
-        w.t0 = b0 + 64 * (i - a.range_off[band]);
-        w.t1 = min(w.t0 + 64, b1);
+        w.t0 = b0 + a.range_len * (i - a.range_off[band]);
+        w.t1 = min(w.t0 + a.range_len, b1);
         // binned targets are ordered by cell, so the cells of the first and the last target bound the rest
         col_first = a.tcell_of[a.tids[w.t0]] - a.tgrid.off[band];
         col_last = a.tcell_of[a.tids[w.t1 - 1]] - a.tgrid.off[band];
@@ -816,13 +817,15 @@ static int ag_knn_tmult(int64_t nt, int nb) {
 // ranges of 64 binned targets; sparse ones by (merged) target cells.
 static bool ag_knn_by_range(int tmult) { return tmult >= 1; }
 // descriptors of a search: one per target cell, or one per range (every band ends with a partial one)
-static int64_t ag_knn_windows_ub(int64_t nt, int nb, int tmult) {
-  return ag_knn_by_range(tmult) ? (nt + 63) / 64 + nb : ag_grid_cells_ub(nb, tmult);
+#define AG_KNN_SELF_RANGE 40  // targets per wave when a sparse set is its own target set (about 16 source cells)
+static int64_t ag_knn_windows_ub(int64_t nt, int nb, int tmult, int range_len = 64) {
+  return ag_knn_by_range(tmult) ? (nt + range_len - 1) / range_len + nb : ag_grid_cells_ub(nb, tmult);
 }
 
 struct AgKnnWs {
   AgBinned src, tgt;
   int tmult;
+  int range_len;
   int* range_off;
   int* queue;
   int* queue_count;
@@ -839,8 +842,12 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   const int tmult = ag_knn_tmult(nt, nb);
   int rc = ag_bin_points(c, d_src, ns, nb, nb, 1, true, stream, w ? &w->src : nullptr);
   if (rc) return rc;
-  rc = ag_bin_points(c, d_tgt, nt, nb, nb, tmult, false, stream, w ? &w->tgt : nullptr);
+  // A set queried against itself (the reference distance, the neighbour lists of the Voronoi cells) is binned once:
+  // the targets are the binned sources, taken in ranges of 64.  (The carve is the same either way.)
+  const bool same_set = w != nullptr && d_src == d_tgt && ns == nt;
+  rc = ag_bin_points(c, d_tgt, nt, nb, nb, tmult, false, stream, (w && !same_set) ? &w->tgt : nullptr);
   if (rc) return rc;
+  if (same_set) w->tgt = w->src;
   const int cap = ag_knn_cap(k, self_query);
   int* queue = c.take<int>(nt);
   int* queue_count = c.take<int>(4);
@@ -848,12 +855,14 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* cand_n = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
   int* cand_t = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
   int* cand_ids = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt * cap) : nullptr;
-  AgWindow* windows = c.take<AgWindow>(ag_knn_windows_ub(nt, nb, tmult) + 1);
+  const int64_t win_a = ag_knn_windows_ub(nt, nb, tmult), win_b = ag_knn_windows_ub(nt, nb, 1, AG_KNN_SELF_RANGE);
+  AgWindow* windows = c.take<AgWindow>((win_a > win_b ? win_a : win_b) + 1);
   int* range_off = c.take<int>(nb + 1);
   if (w) {
     w->windows = windows;
     w->range_off = range_off;
-    w->tmult = tmult;
+    w->tmult = same_set ? 1 : tmult;  // (by ranges of the source binning itself)
+    w->range_len = (same_set && !ag_knn_by_range(tmult)) ? AG_KNN_SELF_RANGE : 64;
     w->queue = queue;
     w->queue_count = queue_count;
     w->max_bits = max_bits;
@@ -909,7 +918,8 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.queue_count = w.queue_count;
   a.windows = w.windows;
   a.by_range = ag_knn_by_range(w.tmult) ? 1 : 0;
-  a.nwin = static_cast<int>(ag_knn_windows_ub(nt, w.tgt.grid.nb, w.tmult));
+  a.range_len = w.range_len;
+  a.nwin = static_cast<int>(ag_knn_windows_ub(nt, w.tgt.grid.nb, w.tmult, w.range_len));
   a.tcell_of = w.tgt.cell_of;
   a.range_off = w.range_off;
   a.self_query = self_query ? 1 : 0;
