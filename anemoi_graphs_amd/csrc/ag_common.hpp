@@ -221,11 +221,15 @@ __device__ __forceinline__ float3 ag_unit_vec(float lat, float lon) {
 // Upper bound of |fp32 chord^2 - true chord^2| when one unit vector comes from ag_unit_vec
 // (coordinate error <= 3e-8) and the other from ag_unit_vec_f32 (<= 2.1e-7): per-coordinate
 // difference error e <= 2.4e-7 + 6e-8 |d|, so |err| <= 2 sqrt(3) e sqrt(c2) + 3 e^2 + roundings.
-__device__ __forceinline__ float ag_chord2_err(float c2) { return 1.0e-6f * sqrtf(c2) + 6.0e-7f * c2 + 4.0e-13f; }
+// (The root is the hardware's, within one ulp and a tenth of the cost of the correctly rounded library root; the
+// coefficient carries that ulp, and a subnormal c2, which the instruction may flush, is below the constant term.)
+__device__ __forceinline__ float ag_chord2_err(float c2) {
+  return 1.0000003e-6f * __builtin_amdgcn_sqrtf(c2) + 6.0e-7f * c2 + 4.0e-13f;
+}
 // The same bound for a chord^2 whose low 8 mantissa bits were replaced by a tag (the value read back
 // with the tag cleared is at most 255 ulp = 3.05e-5 relative below the computed one).
 __device__ __forceinline__ float ag_chord2_err_tagged(float c2) {
-  return 1.0e-6f * sqrtf(c2) + 3.2e-5f * c2 + 4.0e-13f;
+  return 1.0000003e-6f * __builtin_amdgcn_sqrtf(c2) + 3.2e-5f * c2 + 4.0e-13f;
 }
 
 // Enumerate the runs of binned points that can hold a point within angular distance R of any
