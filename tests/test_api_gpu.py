@@ -147,3 +147,22 @@ def test_edge_attribute_types(device, norm, rotated):
     l = EdgeLength(norm=norm).compute(graph, ("test_nodes", "to", "test_nodes"))
     assert isinstance(d, torch.Tensor) and d.shape == (4, 2) and d.dtype == torch.float32
     assert isinstance(l, torch.Tensor) and l.shape == (4, 1) and l.dtype == torch.float32
+
+
+def test_graph_descriptor_on_device_graph(device):
+    """Isolated-node counts of GraphDescriptor.get_edge_summary (describe.py:100-101 of the reference) when the
+    edge lists live on the GPU: ag_mark_ids, equal to torch.unique on the host."""
+    from anemoi_graphs_amd import grids, settings
+    from anemoi_graphs_amd.describe import GraphDescriptor
+    from anemoi_graphs_amd.distributed import ShardedGraphBuilder
+
+    data = torch.from_numpy(grids.octahedral(32)).to(device)
+    with settings.resident(True):
+        graph = ShardedGraphBuilder(data, 3, cutoff_factor=0.6, num_nearest_neighbours=3, x_hops=1).build()
+    rows = {(r[0], r[1]): r for r in GraphDescriptor(graph).get_edge_summary()}
+    for (src, _, dst), store in graph.edge_items():
+        e = store.edge_index.cpu()
+        want_src = graph[src].x.shape[0] - len(torch.unique(e[0]))
+        want_dst = graph[dst].x.shape[0] - len(torch.unique(e[1]))
+        assert rows[(src, dst)][2:5] == [e.shape[1], want_src, want_dst]
+    assert rows[("hidden", "data")][4] == 0  # every data node receives its k nearest hidden nodes
