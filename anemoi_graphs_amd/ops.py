@@ -3,6 +3,7 @@ of the tensors' device and returns device tensors.  PyTorch only provides memory
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 
@@ -34,6 +35,17 @@ def coords(x, device: torch.device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+_NO_SWITCH = contextlib.nullcontext()
+
+
+def _on(device: torch.device):
+    """Context that makes ``device`` current; nothing to enter when it already is (the usual case: entering
+    and leaving torch's device guard costs the host several microseconds per call)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def _ptr(t: torch.Tensor | None):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -55,7 +67,7 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
     if k > ns:
         # what scikit-learn raises in the reference (sklearn/neighbors/_base.py, kneighbors)
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ns}")
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((nt, k), dtype=torch.int32, device=dev)
         dist = torch.empty((nt, k), dtype=torch.float64, device=dev) if return_dist else None
         stats = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -82,7 +94,7 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int) -> torch.Tensor:
     ns, nt = src.shape[0], tgt.shape[0]
     if k > ns:
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ns}")
-    with torch.cuda.device(dev):
+    with _on(dev):
         edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=dev)
         ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
         _lib.check(
@@ -99,7 +111,7 @@ def row_ids(rows: int, k: int, device: torch.device, out: torch.Tensor | None = 
     (written into ``out``, a contiguous int32 device tensor of that length, when given)."""
     lib = _lib.load()
     dev = torch.device(device)
-    with torch.cuda.device(dev):
+    with _on(dev):
         if out is None:
             out = torch.empty(rows * k, dtype=torch.int32, device=dev)
         assert out.dtype == torch.int32 and out.is_contiguous() and out.numel() == rows * k
@@ -115,7 +127,7 @@ def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
     n = x.shape[0]
     if n < 2:
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = 2, n_samples_fit = {n}")
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.zeros((), dtype=torch.float64, device=dev)
         ws = _workspace(lib.ag_nn_maxdist_workspace_bytes(n), dev)
         _lib.check(lib.ag_nn_maxdist(_ptr(x), n, _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "ag_nn_maxdist")
@@ -129,7 +141,7 @@ def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float) -> torch.T
     src, tgt = coords(src, dev), coords(tgt, dev)
     ns, nt = src.shape[0], tgt.shape[0]
     radius = float(radius)
-    with torch.cuda.device(dev):
+    with _on(dev):
         offsets = torch.empty(nt + 2, dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
         _lib.check(
@@ -153,7 +165,7 @@ def sort_edges_(edge_index: torch.Tensor, by_target: bool = True) -> torch.Tenso
     dev = edge_index.device
     assert edge_index.dtype == torch.int32 and edge_index.is_contiguous() and edge_index.shape[0] == 2
     num_edges = edge_index.shape[1]
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _workspace(lib.ag_sort_edges_workspace_bytes(num_edges), dev)
         _lib.check(
             lib.ag_sort_edges(_ptr(edge_index[0]), _ptr(edge_index[1]), num_edges, int(by_target), _ptr(ws), ws.numel(),
@@ -169,7 +181,7 @@ def unique_edges(edge_index: torch.Tensor) -> torch.Tensor:
     dev = device_of(edge_index)
     e = edge_index.to(device=dev, dtype=torch.int32).contiguous().clone()
     num_edges = e.shape[1]
-    with torch.cuda.device(dev):
+    with _on(dev):
         count = torch.zeros((), dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_sort_edges_workspace_bytes(num_edges), dev)
         _lib.check(
@@ -185,7 +197,7 @@ def mask_ids(mask: torch.Tensor, device: torch.device) -> torch.Tensor:
     lib = _lib.load()
     m = torch.as_tensor(mask).reshape(-1).to(device=device, dtype=torch.uint8).contiguous()
     n = m.numel()
-    with torch.cuda.device(device):
+    with _on(device):
         ids = torch.empty(n, dtype=torch.int32, device=device)
         count = torch.zeros((), dtype=torch.int64, device=device)
         ws = _workspace(lib.ag_mask_compact_workspace_bytes(n), device)
@@ -199,7 +211,7 @@ def gather_coords(x: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     dev = x.device
     out = torch.empty((ids.numel(), 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.ag_gather_coords(_ptr(x), _ptr(ids), ids.numel(), _ptr(out), _stream(dev)), "ag_gather_coords")
     return out
 
@@ -208,7 +220,7 @@ def remap_ids_(values: torch.Tensor, id_map: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     dev = values.device
     assert values.dtype == torch.int32 and values.is_contiguous() and id_map.dtype == torch.int32
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.ag_remap_ids(_ptr(values), values.numel(), _ptr(id_map), _stream(dev)), "ag_remap_ids")
     return values
 
@@ -219,7 +231,7 @@ def mark_ids_(mask: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     dev = mask.device
     assert mask.dtype == torch.uint8 and mask.is_contiguous()
     ids = ids.to(device=dev, dtype=torch.int32).contiguous()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.ag_mark_ids(_ptr(ids), ids.numel(), _ptr(mask), mask.numel(), _stream(dev)), "ag_mark_ids")
     return mask
 
@@ -228,7 +240,7 @@ def invert_ids(ids: torch.Tensor, size: int) -> torch.Tensor:
     """int32 [size] map with map[ids[j]] = j and -1 elsewhere."""
     lib = _lib.load()
     dev = ids.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.full((size,), -1, dtype=torch.int32, device=dev)
         _lib.check(lib.ag_invert_ids(_ptr(ids), ids.numel(), _ptr(out), _stream(dev)), "ag_invert_ids")
     return out
@@ -243,7 +255,7 @@ def icosphere(resolution: int, device: torch.device | None = None):
     _lib.check(lib.ag_icosphere_sizes(resolution, ctypes.byref(v), ctypes.byref(f), ctypes.byref(e)),
                "ag_icosphere_sizes")
     nv, nf, ne = v.value, f.value, e.value
-    with torch.cuda.device(dev):
+    with _on(dev):
         xyz = torch.empty((nv, 3), dtype=torch.float64, device=dev)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
         latlon = torch.empty((nv, 2), dtype=torch.float32, device=dev)
@@ -266,7 +278,7 @@ def node_order(latlon: torch.Tensor) -> torch.Tensor:
     dev = device_of(latlon)
     latlon = coords(latlon, dev)
     n = latlon.shape[0]
-    with torch.cuda.device(dev):
+    with _on(dev):
         order = torch.empty(n, dtype=torch.int32, device=dev)
         ws = _workspace(lib.ag_node_order_workspace_bytes(n), dev)
         _lib.check(lib.ag_node_order(_ptr(latlon), n, _ptr(order), _ptr(ws), ws.numel(), _stream(dev)), "ag_node_order")
@@ -280,7 +292,7 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
     dev = rank.device
     lv = (ctypes.c_int32 * len(levels))(*[int(v) for v in levels])
     act = None if active is None else active.to(device=dev, dtype=torch.uint8).contiguous()
-    with torch.cuda.device(dev):
+    with _on(dev):
         if act is None and x_hops == 1 and len(set(int(v) for v in levels)) == len(levels):
             # The complete icosphere: the edge count is a closed form (level l has 30 * 4^l mesh edges, each listed
             # in both directions, and edges of different levels never coincide), so nothing is asked of the device
@@ -322,7 +334,7 @@ def edge_attrs(src_x: torch.Tensor, tgt_x: torch.Tensor, edge_index: torch.Tenso
     src_x, tgt_x = coords(src_x, dev), coords(tgt_x, dev)
     e = edge_index.to(device=dev, dtype=torch.int32).contiguous()
     num_edges = e.shape[1]
-    with torch.cuda.device(dev):
+    with _on(dev):
         length = torch.empty(num_edges, dtype=torch.float32, device=dev) if want_len else None
         direction = torch.empty((num_edges, 2), dtype=torch.float32, device=dev) if want_dir else None
         rng = (torch.empty(lib.ag_len_range_words(), dtype=torch.int32, device=dev)
@@ -352,11 +364,11 @@ def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False,
     assert values.dtype == torch.float32 and values.is_contiguous()
     n = values.numel()
     if value_range is not None and NORMS[norm] in (0, 3, 4):
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.ag_normalise_range(_ptr(values), n, NORMS[norm], int(invert), _ptr(value_range), _stream(dev)),
                        "ag_normalise_range")
         return values
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _workspace(lib.ag_normalise_workspace_bytes(n), dev)
         _lib.check(lib.ag_normalise(_ptr(values), n, NORMS[norm], int(invert), _ptr(ws), ws.numel(), _stream(dev)),
                    "ag_normalise")
@@ -373,7 +385,7 @@ def normalise_f64(values: torch.Tensor, norm: str | None) -> torch.Tensor:
     dev = values.device
     assert values.dtype == torch.float64 and values.is_contiguous()
     n = values.numel()
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty(values.shape, dtype=torch.float32, device=dev)
         ws = _workspace(lib.ag_normalise_workspace_bytes(n), dev)
         _lib.check(lib.ag_normalise_f64(_ptr(values), n, NORMS[norm], _ptr(out), _ptr(ws), ws.numel(), _stream(dev)),
@@ -387,7 +399,7 @@ def radius_rows(src: torch.Tensor, tgt: torch.Tensor, radius: float):
     dev = device_of(src, tgt)
     src, tgt = coords(src, dev), coords(tgt, dev)
     ns, nt = src.shape[0], tgt.shape[0]
-    with torch.cuda.device(dev):
+    with _on(dev):
         offsets = torch.empty(nt + 2, dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
         _lib.check(
@@ -426,7 +438,7 @@ def voronoi_areas(x: torch.Tensor, neighbours: int = VORONOI_NEIGHBOURS, return_
         # what scipy raises in the reference for a degenerate point set (scipy/spatial/_spherical_voronoi.py)
         raise ValueError("Rank of input points must be at least 3")
     k = min(int(neighbours), n, 64)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbr = knn(x, x, k)
         area = torch.empty(n, dtype=torch.float64, device=dev)
         reach = torch.empty(n, dtype=torch.float64, device=dev)
