@@ -1,6 +1,6 @@
 """GPU: randomised parity sweeps against the oracle on uneven node sets (clusters, latitude bands, polar caps, the
 date line): k-NN, radius query and reference distance (tools/fuzz_parity.py), spherical Voronoi cell areas
-(tools/fuzz_voronoi.py), edge attributes (tools/fuzz_attrs.py), meshes and multi-scale edges (tools/fuzz_mesh.py).  The tools also run longer sweeps from the command line."""
+(tools/fuzz_voronoi.py), edge attributes (tools/fuzz_attrs.py), meshes and multi-scale edges (tools/fuzz_mesh.py), k-NN on dense target sets (tools/fuzz_dense.py).  The tools also run longer sweeps from the command line."""
 import importlib.util
 from pathlib import Path
 
@@ -41,3 +41,9 @@ def test_randomised_primitive_sweep(device):
     """unique / sort / compact / gather / remap / mark / invert against numpy; masked KNNEdges and
     RemoveUnconnectedNodes against the oracle."""
     assert _tool("fuzz_ops").run(60, seed0=5000) == 0
+
+
+def test_randomised_dense_target_sweep(device):
+    """k-NN on dense target sets (the decoder's regime, stage 1 by ranges of 64 binned targets): uneven
+    densities, bands, polar caps, regular grids with coincident pole rows -- every row against the oracle."""
+    assert _tool("fuzz_dense").run(6, seed0=6000) == 0
