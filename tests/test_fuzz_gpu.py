@@ -47,3 +47,9 @@ def test_randomised_dense_target_sweep(device):
     """k-NN on dense target sets (the decoder's regime, stage 1 by ranges of 64 binned targets): uneven
     densities, bands, polar caps, regular grids with coincident pole rows -- every row against the oracle."""
     assert _tool("fuzz_dense").run(6, seed0=6000) == 0
+
+
+def test_randomised_dense_source_radius_sweep(device):
+    """Cut-off search in the encoder's regime: dense uneven sources around a sparse target set, rows from empty
+    to tens of thousands of entries, exact edge lists and (target, source) order against the oracle."""
+    assert _tool("fuzz_dense").run_radius(8, seed0=7000) == 0
