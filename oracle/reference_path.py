@@ -264,6 +264,31 @@ def stretched_tri_nodes(base_resolution: int, lam_resolution: int, reference_coo
     return coords[order].astype(np.float32), order, coords
 
 
+def multiscale_edges_one_hop(resolutions: list[int], node_ordering: np.ndarray) -> np.ndarray:
+    """The x_hops = 1 case of ``multiscale_edges`` on the complete icosphere (TriNodes), in numpy only, for
+    meshes too large for the per-vertex networkx loop (r7: 163,842 vertices).
+
+    With one hop the neighbours of a level-l vertex are the other ends of its level-l mesh edges
+    (generate/tri_icosahedron.py:212-224: ego_graph(radius=1, center=False) of the graph built from
+    ``edges_unique``), so a level contributes both directions of every unique mesh edge; the level's vertices
+    map to the final mesh's nodes with the same vertex id (:185: nearest final-mesh node of a vertex that is
+    itself a vertex of the final mesh), and node ids are positions in ``node_ordering`` (edges/builder.py:453).
+    The DiGraph merges the levels (:187).  ``tests/test_oracle_golden.py`` proves this function equal to the
+    networkx restatement on the meshes that one handles.  Returns int32 [2,E] sorted by (target, source)."""
+    from . import icosphere as ico
+
+    node_ordering = np.asarray(node_ordering)
+    rank = np.empty(len(node_ordering), dtype=np.int64)
+    rank[node_ordering] = np.arange(len(node_ordering))
+    pairs = []
+    for resolution in sorted(set(int(r) for r in resolutions)):
+        _, f = ico.icosphere(resolution)
+        e = np.unique(ico.face_edges(f), axis=0)
+        pairs.append(np.concatenate([rank[e], rank[e[:, ::-1]]], axis=0))
+    pairs = np.unique(np.concatenate(pairs, axis=0), axis=0)  # columns (source, target)
+    return canonical_sort(pairs.T.astype(np.int32))
+
+
 def multiscale_edges(resolutions: list[int], x_hops: int, node_ordering: np.ndarray, node_coords: np.ndarray | None = None,
                      mask_reference: np.ndarray | None = None, margin_radius_km: float = 100.0) -> np.ndarray:
     """add_edges_to_nx_graph (generate/tri_icosahedron.py:165-188), get_neighbours_within_hops

@@ -21,24 +21,39 @@ DOC_FACES = {0: 20, 1: 80, 2: 320, 3: 1280, 4: 5120, 5: 20480, 6: 81920}
 DOC_MULTILEVEL_EDGES = {0: 60, 1: 300, 2: 1260, 3: 5100, 4: 20460, 5: 81900, 6: 327660}
 
 
-@pytest.mark.parametrize("r", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("r", [0, 1, 2, 3, 5, 6, 7])
 def test_icosphere_matches_restatement(device, r):
+    """Vertices, faces and per-level edges bit-equal to the numpy restatement of trimesh, up to the headline
+    mesh (r7); lat/lon within one float32 ulp (device asin / atan2 against the host libm's), with the number of
+    differing values reported; node order equal to the canonical order of the restatement's coordinates on every
+    node whose coordinates are bit-equal, and equal to the canonical order of the kernel's own coordinates."""
     xyz, faces, latlon, order, rank, level_edges = [t.cpu().numpy() for t in ops.icosphere(r, device)]
     v, f = ico.icosphere(r)
-    assert xyz.shape == (DOC_NODES[r], 3) and faces.shape == (DOC_FACES[r], 3)
+    nodes = 10 * 4**r + 2
+    assert xyz.shape == (nodes, 3) and faces.shape == (20 * 4**r, 3)
+    if r in DOC_NODES:
+        assert nodes == DOC_NODES[r] and faces.shape[0] == DOC_FACES[r]
     assert np.array_equal(faces, f)
     assert np.array_equal(xyz, v), np.abs(xyz - v).max()  # same IEEE operations in the same order
     coords = ico.latlon_rad(v)
     want_order = rp.coordinates_ordering_canonical(coords)
-    # asin/atan2 come from different libms: allow a last-bit float32 difference, count it
-    got = latlon
-    want = coords[want_order]
-    ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-    assert ulp.max() <= 1, ulp.max()
-    if ulp.max() == 0:
-        assert np.array_equal(order, want_order)
     assert np.array_equal(rank[order], np.arange(len(order)))
-    assert np.all(np.diff(got[:, 0]) <= 0)  # latitude descending
+    # by vertex: asin/atan2 come from different libms -- allow a last-bit float32 difference, count it
+    got_by_vertex = latlon[rank]
+    ulp = np.abs(got_by_vertex.view(np.int32).astype(np.int64) - coords.view(np.int32).astype(np.int64))
+    differing = int((ulp > 0).sum())
+    print(f"r{r}: {differing} of {ulp.size} float32 lat/lon values differ from numpy's (max {ulp.max()} ulp)")
+    assert ulp.max() <= 1, ulp.max()
+    # the order IS the canonical order of the coordinates the kernel stored ...
+    assert np.array_equal(order, rp.coordinates_ordering_canonical(got_by_vertex))
+    # ... and the restatement's order on all vertices whose two coordinates are bit-equal (a vertex whose
+    # latitude or longitude differs in the last bit may sit elsewhere among its near-ties; the others keep
+    # their relative order)
+    same = (ulp == 0).all(axis=1)
+    assert np.array_equal(order[same[order]], want_order[same[want_order]])
+    if differing == 0:
+        assert np.array_equal(order, want_order) and np.array_equal(latlon, coords[want_order])
+    assert np.all(np.diff(latlon[:, 0]) <= 0)  # latitude descending
     # per-level unique edges: level l at offset 10 * (4**l - 1), as (max << 32 | min) keys
     for l in range(r + 1):
         fl = ico.icosphere(l)[1]
@@ -102,6 +117,52 @@ def test_multiscale_live_oracle(device, r, hops):
     e = ops.multiscale_edges(r, list(range(r + 1)), hops, rank, level_edges).cpu().numpy()
     want = rp.multiscale_edges(list(range(r + 1)), hops, order.cpu().numpy())
     assert np.array_equal(e, h.canonical(want))
+
+
+@pytest.mark.parametrize("r,levels", [(5, None), (6, None), (7, None), (7, [0, 3, 7]), (7, [7]), (6, [2, 5, 6]),
+                                      (7, [1, 2, 3, 4, 5, 6, 7])])
+def test_multiscale_one_hop_oracle_full_size(device, r, levels):
+    """x_hops = 1 on the meshes of the benchmark configurations (r6, r7 = the headline mesh), all levels and
+    level subsets, every edge compared with the numpy oracle (proved equal to the networkx restatement of
+    generate/tri_icosahedron.py:165-188 on small meshes by tests/test_oracle_golden.py).  The closed-form row
+    placement takes a different path per level count; r7 exercises the one the benchmark runs."""
+    levels = list(range(r + 1)) if levels is None else levels
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(r, device)
+    e = ops.multiscale_edges(r, levels, 1, rank, level_edges).cpu().numpy()
+    want = rp.multiscale_edges_one_hop(levels, order.cpu().numpy())
+    assert e.shape == want.shape == (2, sum(60 * 4**l for l in levels))
+    assert np.array_equal(e, want)
+    # the general (counting) path on the same mesh gives the same list
+    lv = (ops.ctypes.c_int32 * len(levels))(*levels)
+    count = torch.zeros((), dtype=torch.int64, device=device)
+    lib = ops._lib.load()
+    ws = ops._workspace(lib.ag_multiscale_workspace_bytes(r, len(levels), 1), device)
+    ops._lib.check(lib.ag_multiscale_count(r, lv, len(levels), 1, ops._ptr(rank), None, ops._ptr(level_edges),
+                                           ops._ptr(count), ops._ptr(ws), ws.numel(), ops._stream(device)), "count")
+    n = int(count.item())
+    e2 = torch.empty((2, n), dtype=torch.int32, device=device)
+    ops._lib.check(lib.ag_multiscale_fill(r, lv, len(levels), 1, n, ops._ptr(e2[0]), ops._ptr(e2[1]), ops._ptr(ws),
+                                          ws.numel(), ops._stream(device)), "fill")
+    assert np.array_equal(e2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("r", [1, 3, 6, 7])
+def test_level_edges_are_stored_as_the_placement_assumes(device, r):
+    """The closed-form row placement reads slot numbers off the ORDER in which ag_icosphere stores the edges of a
+    level (sorted by (max, min) below the finest level; split pairs, then central-face sides on the finest).
+    tools/ms_place_replay.py replays the scheme on the host from the oracle's meshes in that order; this test
+    pins that the device arrays are in exactly that order, element for element."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location(
+        "ms_place_replay", Path(__file__).resolve().parents[1] / "tools" / "ms_place_replay.py")
+    replay = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(replay)
+    level_edges = ops.icosphere(r, device)[5].cpu().numpy()
+    for l, e in enumerate(replay.level_edge_arrays_vec(r)):
+        keys = level_edges[10 * (4**l - 1): 10 * (4 ** (l + 1) - 1)]
+        assert np.array_equal(keys & 0xFFFFFFFF, e[:, 0]) and np.array_equal(keys >> 32, e[:, 1]), l
 
 
 def test_multiscale_counts_and_symmetry_r7(device):

@@ -81,6 +81,23 @@ def test_tri_nodes_and_multiscale(golden, r, hops):
     assert np.array_equal(h.canonical(e), h.canonical(want))
 
 
+@pytest.mark.parametrize("r,levels", [(0, [0]), (1, [0, 1]), (2, [0, 1, 2]), (3, [0, 1, 2, 3]), (3, [0, 2, 3]), (3, [3]),
+                                      (4, [0, 1, 2, 3, 4]), (4, [1, 4])])
+def test_one_hop_oracle_equals_networkx_restatement(golden, r, levels):
+    """The numpy-only x_hops = 1 oracle (used for the r6 / r7 meshes the networkx loop cannot handle in test
+    time) is the same function as the networkx restatement wherever that one runs, and through it equal to
+    the reference's own output (golden fixtures, r <= 3)."""
+    order = rp.tri_nodes(r)[1]
+    fast = rp.multiscale_edges_one_hop(levels, order)
+    slow = rp.multiscale_edges(levels, 1, order)
+    assert np.array_equal(fast, h.canonical(slow))
+    assert fast.shape[1] == sum(60 * 4**l for l in levels)
+    if levels == list(range(r + 1)) and r <= 3:
+        g = golden("tri_multiscale")
+        want = _relabel(g[f"r{r}_x"], g[f"r{r}_h1_edge_index"], rp.tri_nodes(r)[0])
+        assert np.array_equal(fast, h.canonical(want))
+
+
 def _same_nodes(x, ref_x):
     assert x.shape == ref_x.shape
     assert np.array_equal(x[np.lexsort((x[:, 1], x[:, 0]))], ref_x[np.lexsort((ref_x[:, 1], ref_x[:, 0]))])
