@@ -40,13 +40,13 @@ SIGNATURES = {
     "ag_multiscale_complete_edges": (c_int64, [ctypes.POINTER(ctypes.c_int32), c_int]),
     "ag_multiscale_complete": (
         c_int, [c_int, ctypes.POINTER(ctypes.c_int32), c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "ag_edge_attrs": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P]),
-    "ag_edge_attrs_range": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "ag_edge_attrs": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "ag_edge_attrs_range": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),
     "ag_len_range_words": (c_size_t, []),
     "ag_normalise_range": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "ag_normalise_workspace_bytes": (c_size_t, [c_int64]),
     "ag_normalise": (c_int, [_P, c_int64, c_int, c_int, _P, c_size_t, _P]),
-    "ag_normalise_f64": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "ag_normalise_f64": (c_int, [_P, c_int64, c_int, _P, c_int, _P, c_size_t, _P]),
     "ag_voronoi_areas_knn": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P]),
     "ag_voronoi_far_workspace_bytes": (c_size_t, [c_int64]),
     "ag_voronoi_areas_far": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
@@ -56,12 +56,12 @@ SIGNATURES = {
     "ag_unique_edges": (c_int, [_P, _P, c_int64, _P, _P, c_size_t, _P]),
     "ag_mask_compact_workspace_bytes": (c_size_t, [c_int64]),
     "ag_mask_compact": (c_int, [_P, c_int64, _P, _P, _P, c_size_t, _P]),
-    "ag_gather_coords": (c_int, [_P, _P, c_int64, _P, _P]),
-    "ag_remap_ids": (c_int, [_P, c_int64, _P, _P]),
+    "ag_gather_coords": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P]),
+    "ag_remap_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     "ag_node_order_workspace_bytes": (c_size_t, [c_int64]),
     "ag_node_order": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
-    "ag_mark_ids": (c_int, [_P, c_int64, _P, c_int64, _P]),
-    "ag_invert_ids": (c_int, [_P, c_int64, _P, _P]),
+    "ag_mark_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
+    "ag_invert_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     "ag_fill_row_ids": (c_int, [_P, c_int64, c_int, _P]),
 }
 

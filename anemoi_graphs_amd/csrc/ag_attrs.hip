@@ -150,7 +150,7 @@ __device__ __forceinline__ void ag_attr_target(float2 tp, bool rotated, AgAttrRu
 // One edge: utils.haversine_distance (utils.py:99-103) in float32 and the direction of the
 // rotated source with respect to the pole (edges/directional.py:68-94).
 __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int r, bool rotated, bool want_len,
-                                             bool want_dir, const AgAtanCoef& K, float* len, float2* dir) {
+                                             bool want_dir, const AgAtanCoef& K, float* len, double2* dir) {
   const float tlat = R.lat[r], tlon = R.lon[r];
   float ss, cs;
   ag_np_sincos_f32(sp.x, &ss, &cs);
@@ -166,7 +166,7 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
   }
   if (want_dir) {
     if (!rotated) {
-      *dir = make_float2(tlat - sp.x, tlon - sp.y);
+      *dir = make_double2(static_cast<double>(tlat - sp.x), static_cast<double>(tlon - sp.y));
       return;
     }
     float so, co;
@@ -186,7 +186,7 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
       m2 = __builtin_fma(dx, dx, dy * dy);
     }
     const double inv = ag_rsqrt_f64(m2);
-    *dir = make_float2(static_cast<float>(dx * inv), static_cast<float>(dy * inv));
+    *dir = make_double2(dx * inv, dy * inv);
   }
 }
 
@@ -203,10 +203,12 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
                                                             const int32_t* __restrict__ es,
                                                             const int32_t* __restrict__ et, int64_t E, int flags,
                                                             float* __restrict__ out_len, float2* __restrict__ out_dir,
-                                                            unsigned* __restrict__ len_range, const AgAtanCoef K) {
+                                                            unsigned* __restrict__ len_range, const AgAtanCoef K,
+                                                            int ns_last, int nt_last, int* __restrict__ bad) {
   __shared__ AgAttrRuns R_all[4];
   const bool rotated = (flags & AG_ATTR_ROTATED) != 0 && out_dir != nullptr;
   const bool want_len = out_len != nullptr, want_dir = out_dir != nullptr;
+  const bool dir_f64 = (flags & AG_ATTR_DIR_F64) != 0;  // out_dir holds float64 pairs
   const int lane = ag_lane();
   AgAttrRuns& R = R_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -241,12 +243,18 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     }
     return r;
   };
+  // An id outside its node set (the reference's numpy indexing raises IndexError for it,
+  // edges/attributes.py:144-148) is never followed: the gather reads the nearest valid row instead, the
+  // edge's values are meaningless and the caller's error word is set.
+  bool bad_id = false;
   auto gather = [&](const Ids& ids) {
     Ends g;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      g.sp[j] = src_x[ids.s[j]];
-      g.tp[j] = tgt_x[ids.t[j]];
+      const int s = min(max(ids.s[j], 0), ns_last), t = min(max(ids.t[j], 0), nt_last);
+      bad_id = bad_id || s != ids.s[j] || t != ids.t[j];
+      g.sp[j] = src_x[s];
+      g.tp[j] = tgt_x[t];
       g.first[j] = (j * 64 + lane == 0) || ids.p[j] != ids.t[j];
     }
     return g;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     for (int j = 0; j < 2; ++j) {
       if (!valid[j]) continue;
       float len;
-      float2 dir;
+      double2 dir;
       ag_attr_edge(g.sp[j], R, run[j], rotated, want_len, want_dir, K, &len, &dir);
       if (want_len) {
         len_c[j * 64 + lane] = len;
@@ -294,7 +302,10 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
         hi_bits = max(hi_bits, b);
         lo_inv_bits = max(lo_inv_bits, (b > 0x7f800000u) ? 0u : ~b);  // (a NaN is seen through the maximum)
       }
-      if (want_dir) dir_c[j * 64 + lane] = dir;
+      if (want_dir) {
+        if (dir_f64) reinterpret_cast<double2*>(out_dir)[base + j * 64 + lane] = dir;
+        else dir_c[j * 64 + lane] = make_float2(static_cast<float>(dir.x), static_cast<float>(dir.y));
+      }
     }
     ag_lds_wave_sync();  // the staged runs are overwritten by the next chunk
   };
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
     ids = fetch_ids(chunk + 3 * nwaves);
     process(chunk + nwaves, gb);
   }
+  if (bad_id && bad != nullptr) *bad = 1;  // (every writer stores the same value)
   if (len_range != nullptr && want_len) {
     // every wave that had a chunk leaves its range in a slot of its own (atomics of thousands of waves on
     // one word are far slower than the kernel); ag_len_range_finish_kernel folds the slots
@@ -354,15 +366,18 @@ __global__ __launch_bounds__(1024) void ag_len_range_finish_kernel(unsigned* __r
 
 extern "C" int ag_edge_attrs_range(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt,
                                    const int32_t* d_edge_src, const int32_t* d_edge_tgt, int64_t E, int flags,
-                                   float* d_len, float* d_dir, uint32_t* d_len_range, void* stream) {
+                                   float* d_len, float* d_dir, uint32_t* d_len_range, int32_t* d_bad, void* stream) {
   AG_REQUIRE(E >= 0 && ns >= 0 && nt >= 0, "ag_edge_attrs: negative size");
+  AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31), "ag_edge_attrs: node counts must fit int32");
+  AG_REQUIRE(E == 0 || (ns > 0 && nt > 0), "ag_edge_attrs: %lld edges between node sets of %lld and %lld nodes",
+             static_cast<long long>(E), static_cast<long long>(ns), static_cast<long long>(nt));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool want_range = d_len_range != nullptr && d_len != nullptr;
   const bool empty = E == 0 || (d_len == nullptr && d_dir == nullptr);
   if (!empty) {
     AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
     const int blocks = ag_blocks(E, 4 * AG_ATTR_CHUNK, AG_ATTR_MAX_BLOCKS);
-    AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(blocks), dim3(256), s, reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), want_range ? d_len_range : nullptr, AG_ATAN_COEF);
+    AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(blocks), dim3(256), s, reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), want_range ? d_len_range : nullptr, AG_ATAN_COEF, static_cast<int>(ns - 1), static_cast<int>(nt - 1), d_bad);
     AG_LAUNCH_CHECK();
   }
   if (d_len_range != nullptr) {
@@ -380,8 +395,9 @@ extern "C" size_t ag_len_range_words(void) { return 2 * (1 + size_t(AG_ATTR_MAX_
 
 extern "C" int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt,
                              const int32_t* d_edge_src, const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len,
-                             float* d_dir, void* stream) {
-  return ag_edge_attrs_range(d_src_x, ns, d_tgt_x, nt, d_edge_src, d_edge_tgt, E, flags, d_len, d_dir, nullptr, stream);
+                             float* d_dir, int32_t* d_bad, void* stream) {
+  return ag_edge_attrs_range(d_src_x, ns, d_tgt_x, nt, d_edge_src, d_edge_tgt, E, flags, d_len, d_dir, nullptr, d_bad,
+                             stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -597,7 +613,8 @@ __global__ __launch_bounds__(256) void ag_reduce_partial_f64_kernel(const double
 
 __global__ __launch_bounds__(256) void ag_normalise_apply_f64_kernel(const double* __restrict__ v, int64_t n, int norm,
                                                                      const AgStats* __restrict__ stats,
-                                                                     float* __restrict__ out) {
+                                                                     float* __restrict__ out,
+                                                                     double* __restrict__ out64) {
   double scale = 1.0, shift = 0.0;
   if (norm == 1) scale = stats->sum;
   else if (norm == 2) scale = sqrt(stats->sumsq);
@@ -610,11 +627,15 @@ __global__ __launch_bounds__(256) void ag_normalise_apply_f64_kernel(const doubl
     if (scale == 0.0) scale = 1.0;  // the reference leaves the values untouched when the std is 0
   }
   const int64_t tid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
-  for (int64_t i = tid; i < n; i += nthreads) out[i] = static_cast<float>((v[i] - shift) / scale);
+  for (int64_t i = tid; i < n; i += nthreads) {
+    const double r = (v[i] - shift) / scale;
+    if (out64 != nullptr) out64[i] = r;
+    else out[i] = static_cast<float>(r);
+  }
 }
 
-extern "C" int ag_normalise_f64(const double* d_values, int64_t n, int norm, float* d_out, void* d_ws, size_t ws_bytes,
-                                void* stream) {
+extern "C" int ag_normalise_f64(const double* d_values, int64_t n, int norm, void* d_out, int out_f64, void* d_ws,
+                                size_t ws_bytes, void* stream) {
   AG_REQUIRE(norm >= 0 && norm <= 5, "ag_normalise_f64: unknown normalisation %d", norm);
   AG_REQUIRE(n >= 0, "ag_normalise_f64: negative size");
   if (n == 0) return AG_OK;
@@ -634,7 +655,7 @@ extern "C" int ag_normalise_f64(const double* d_values, int64_t n, int norm, flo
       AG_LAUNCH_CHECK();
     }
   }
-  AG_KERNEL("ag_normalise_apply_f64_kernel", ag_normalise_apply_f64_kernel, dim3(ag_blocks(n, 256 * 4, 1 << 14)), dim3(256), s, d_values, n, norm, stats, d_out);
+  AG_KERNEL("ag_normalise_apply_f64_kernel", ag_normalise_apply_f64_kernel, dim3(ag_blocks(n, 256 * 4, 1 << 14)), dim3(256), s, d_values, n, norm, stats, out_f64 ? nullptr : static_cast<float*>(d_out), out_f64 ? static_cast<double*>(d_out) : nullptr);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -429,27 +429,46 @@ extern "C" int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids,
   return AG_OK;
 }
 
-__global__ void ag_gather_coords_kernel(const float2* __restrict__ x, const int32_t* __restrict__ ids, int64_t n,
-                                        float2* __restrict__ out) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    out[i] = x[ids[i]];
+// Ids that index a table are checked against its length in every kernel below: an id outside [0, length) is
+// never followed (the entry is skipped, or filled with a fixed value), and the caller's error word *bad is
+// set to 1 -- every writer stores the same value.  numpy / torch raise IndexError for such an id in the
+// reference; the host side of this library does so when it reads the word.
+__global__ void ag_gather_coords_kernel(const float2* __restrict__ x, int64_t n_x, const int32_t* __restrict__ ids,
+                                        int64_t n, float2* __restrict__ out, int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int32_t id = ids[i];
+    const bool ok = id >= 0 && id < n_x;
+    out[i] = ok ? x[id] : make_float2(0.0f, 0.0f);
+    if (!ok && bad != nullptr) *bad = 1;
+  }
 }
 
-extern "C" int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream) {
-  if (n <= 0) return AG_OK;
-  AG_KERNEL("ag_gather_coords_kernel", ag_gather_coords_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_x), d_ids, n, reinterpret_cast<float2*>(d_out));
+extern "C" int ag_gather_coords(const float* d_x, int64_t n_x, const int32_t* d_ids, int64_t n, float* d_out,
+                                int32_t* d_bad, void* stream) {
+  AG_REQUIRE(n >= 0 && n_x >= 0, "ag_gather_coords: negative size");
+  if (n == 0) return AG_OK;
+  AG_REQUIRE(d_ids && d_out && (d_x || n_x == 0), "ag_gather_coords: null pointer");
+  AG_KERNEL("ag_gather_coords_kernel", ag_gather_coords_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(d_x), n_x, d_ids, n, reinterpret_cast<float2*>(d_out), d_bad);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
 
-__global__ void ag_remap_ids_kernel(int32_t* __restrict__ v, int64_t n, const int32_t* __restrict__ map) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    v[i] = map[v[i]];
+__global__ void ag_remap_ids_kernel(int32_t* __restrict__ v, int64_t n, const int32_t* __restrict__ map, int64_t n_map,
+                                    int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int32_t id = v[i];
+    const bool ok = id >= 0 && id < n_map;
+    v[i] = ok ? map[id] : -1;
+    if (!ok && bad != nullptr) *bad = 1;
+  }
 }
 
-extern "C" int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream) {
-  if (n <= 0) return AG_OK;
-  AG_KERNEL("ag_remap_ids_kernel", ag_remap_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), static_cast<hipStream_t>(stream), d_values, n, d_map);
+extern "C" int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, int64_t n_map, int32_t* d_bad,
+                            void* stream) {
+  AG_REQUIRE(n >= 0 && n_map >= 0, "ag_remap_ids: negative size");
+  if (n == 0) return AG_OK;
+  AG_REQUIRE(d_values && (d_map || n_map == 0), "ag_remap_ids: null pointer");
+  AG_KERNEL("ag_remap_ids_kernel", ag_remap_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), static_cast<hipStream_t>(stream), d_values, n, d_map, n_map, d_bad);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -593,27 +612,34 @@ __global__ void ag_mark_ids_kernel(const int32_t* __restrict__ ids, int64_t n, u
   }
 }
 
-extern "C" int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, void* stream) {
+extern "C" int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, int32_t* d_bad,
+                           void* stream) {
   AG_REQUIRE(n >= 0 && n_mask >= 0, "ag_mark_ids: negative size");
   if (n == 0) return AG_OK;
-  AG_REQUIRE(d_ids && d_mask, "ag_mark_ids: null pointer");
+  AG_REQUIRE(d_ids && (d_mask || n_mask == 0), "ag_mark_ids: null pointer");
   AG_KERNEL("ag_mark_ids_kernel", ag_mark_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256),
-            static_cast<hipStream_t>(stream), d_ids, n, d_mask, n_mask, static_cast<int*>(nullptr));
+            static_cast<hipStream_t>(stream), d_ids, n, d_mask, n_mask, d_bad);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
 
-__global__ void ag_invert_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int32_t* __restrict__ map) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    map[ids[i]] = static_cast<int32_t>(i);
+__global__ void ag_invert_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int32_t* __restrict__ map,
+                                     int64_t n_map, int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int32_t id = ids[i];
+    if (id >= 0 && id < n_map) map[id] = static_cast<int32_t>(i);
+    else if (bad != nullptr) *bad = 1;
+  }
 }
 
-extern "C" int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, void* stream) {
-  AG_REQUIRE(n >= 0, "ag_invert_ids: negative size");
+extern "C" int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, int64_t n_map, int32_t* d_bad,
+                             void* stream) {
+  AG_REQUIRE(n >= 0 && n_map >= 0, "ag_invert_ids: negative size");
+  AG_REQUIRE(n < (int64_t(1) << 31), "ag_invert_ids: positions must fit int32");
   if (n == 0) return AG_OK;
-  AG_REQUIRE(d_ids && d_map, "ag_invert_ids: null pointer");
+  AG_REQUIRE(d_ids && (d_map || n_map == 0), "ag_invert_ids: null pointer");
   AG_KERNEL("ag_invert_ids_kernel", ag_invert_ids_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256),
-            static_cast<hipStream_t>(stream), d_ids, n, d_map);
+            static_cast<hipStream_t>(stream), d_ids, n, d_map, n_map, d_bad);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -32,8 +32,9 @@ class GraphDescriptor:
     def __init__(self, path: str | Path | HeteroData, **kwargs):
         if isinstance(path, (str, Path)):
             self.path = path
-            # a file this package wrote itself (GraphCreator.save): the container object is pickled with it
-            self.graph = torch.load(path, weights_only=False)
+            from .hetero import load_graph
+
+            self.graph = load_graph(path)
         else:
             self.path = None
             self.graph = path

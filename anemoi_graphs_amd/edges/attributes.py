@@ -28,6 +28,10 @@ class BaseEdgeAttribute(ABC, NormaliserMixin):
     def post_process(self, values: torch.Tensor) -> torch.Tensor:
         if values.ndim == 1:
             values = values[:, None]
+        if values.dtype == torch.float64:
+            # normalised in float64 and rounded to float32 afterwards, as the reference treats a float64 array
+            # (edges/attributes.py:33-40: normalise(values) then astype(float32))
+            return place(ops.normalise_f64(values.contiguous(), self.norm))
         return place(self.normalise(values.contiguous()))
 
     def check_nodes(self, graph: HeteroData, edges_name: tuple[str, str, str]) -> None:
@@ -54,13 +58,14 @@ def compute_fused(graph: HeteroData, edges_name: tuple[str, str, str], attribute
     lengths = [a for a in attributes.values() if type(a) is EdgeLength]
     directions = [a for a in attributes.values() if type(a) is EdgeDirection]
     raw_len = raw_dir = len_range = None
-    if lengths and directions and len({d.luse_rotated_features for d in directions}) == 1:
+    if lengths and directions and len({(d.luse_rotated_features, d.wants_float64) for d in directions}) == 1:
         for a in attributes.values():
             a.check_nodes(graph, edges_name)
         edge_index = graph[edges_name].edge_index
         # (the kernel also reports the range of the lengths: unit-max / unit-range need no reduction pass)
         raw_len, raw_dir, len_range = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index,
-                                                     rotated=directions[0].luse_rotated_features, len_range=True)
+                                                     rotated=directions[0].luse_rotated_features, len_range=True,
+                                                     dir_f64=directions[0].wants_float64)
     out = {}
     n_len, n_dir = len(lengths), len(directions)
     for name, a in attributes.items():
@@ -83,10 +88,18 @@ class EdgeDirection(BaseEdgeAttribute):
         super().__init__(norm)
         self.luse_rotated_features = luse_rotated_features
 
+    @property
+    def wants_float64(self) -> bool:
+        """The reference's rotated directions are a float64 array that is normalised before it is rounded to
+        float32 (edges/directional.py:57-65, edges/attributes.py:33-40).  For the normalisations that only
+        scale, rounding first changes a result by float32 roundings; `unit-range` subtracts the minimum, which
+        cancels, so it is applied to the float64 values here too."""
+        return self.luse_rotated_features and self.norm == "unit-range"
+
     def get_raw_values(self, graph: HeteroData, source_name: str, target_name: str) -> torch.Tensor:
         edge_index = graph[(source_name, "to", target_name)].edge_index
         _, direction = ops.edge_attrs(graph[source_name].x, graph[target_name].x, edge_index, want_len=False,
-                                      rotated=self.luse_rotated_features)
+                                      rotated=self.luse_rotated_features, dir_f64=self.wants_float64)
         return direction
 
 

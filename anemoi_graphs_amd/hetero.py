@@ -80,3 +80,75 @@ except ImportError:
                 lines.append("  },")
             lines.append(")")
             return "\n".join(lines)
+
+
+# ---------------------------------------------------------------------------------------------------
+# graph files
+# ---------------------------------------------------------------------------------------------------
+PORTABLE_FORMAT = "anemoi_graphs_amd.graph/1"
+
+
+def to_host(graph):
+    """Move every device tensor of the graph to host memory, in place (a graph file must load without a GPU)."""
+    import torch
+
+    for name in [*graph.node_types, *graph.edge_types]:
+        store = graph[name]
+        for key in list(store.keys()):
+            value = store[key]
+            if isinstance(value, torch.Tensor) and value.is_cuda:
+                store[key] = value.cpu()
+    return graph
+
+
+def to_portable(graph) -> dict:
+    """The graph as plain containers -- dicts, lists, strings, numbers and tensors only -- which ``torch.load``
+    reads back with ``weights_only=True`` and without this package."""
+    return {
+        "format": PORTABLE_FORMAT,
+        "nodes": {name: dict(graph[name].items()) for name in graph.node_types},
+        "edges": [{"source": s, "relation": r, "target": t, "attributes": dict(graph[(s, r, t)].items())}
+                  for (s, r, t) in graph.edge_types],
+    }
+
+
+def from_portable(content: dict):
+    """``HeteroData`` (torch_geometric's when it is installed, so this is also the converter to the class the
+    reference's consumers expect) from the output of ``to_portable``."""
+    if not isinstance(content, dict) or content.get("format") != PORTABLE_FORMAT:
+        raise ValueError("not a graph written by anemoi_graphs_amd.hetero.save_graph")
+    graph = HeteroData()
+    for name, attributes in content["nodes"].items():
+        for key, value in attributes.items():
+            graph[name][key] = value
+    for edge_set in content["edges"]:
+        store = graph[(edge_set["source"], edge_set["relation"], edge_set["target"])]
+        for key, value in edge_set["attributes"].items():
+            store[key] = value
+    return graph
+
+
+def save_graph(graph, path) -> None:
+    """With torch_geometric installed the graph is a ``torch_geometric.data.HeteroData`` and is written as the
+    reference writes it, ``torch.save(graph, path)`` (create.py:158): the file anemoi-training loads.  Without
+    torch_geometric the container is this module's stand-in, which no other program could unpickle: the graph is
+    then written as plain containers (``to_portable``), and ``load_graph`` -- on a machine that has
+    torch_geometric -- turns it into the real class."""
+    import torch
+
+    torch.save(graph if HAVE_TORCH_GEOMETRIC else to_portable(graph), path)
+
+
+def load_graph(path):
+    """Read a graph file: the portable form (nothing in the file is executed), else a pickled HeteroData."""
+    import pickle
+
+    import torch
+
+    try:
+        content = torch.load(path, weights_only=True)
+    except pickle.UnpicklingError:
+        # a pickled container object (the reference's format): loading it runs the pickle, as torch_geometric's
+        # own users do for graph.pt -- only for files from a source the caller trusts
+        return torch.load(path, weights_only=False)
+    return from_portable(content)

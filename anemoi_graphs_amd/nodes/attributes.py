@@ -20,7 +20,15 @@ from ..utils import place
 
 LOGGER = logging.getLogger(__name__)
 
-_TORCH_DTYPES = {"float32": torch.float32, "float64": torch.float64, "float16": torch.float16, "bool": torch.bool}
+
+
+def _torch_dtype(dtype) -> torch.dtype:
+    """The torch dtype of anything numpy's ``astype`` accepts ("float32", "f8", "float", np.float16, ...)."""
+    name = np.dtype(dtype).name  # TypeError "data type ... not understood" for an unknown name, as astype raises
+    if not hasattr(torch, name):
+        raise TypeError(f"data type {dtype!r} has no torch counterpart")
+    return getattr(torch, name)
+
 
 
 class BaseNodeAttribute(ABC):
@@ -48,12 +56,12 @@ class BaseNodeAttribute(ABC):
         values = values.to(torch.float64).contiguous()
         if not values.is_cuda:
             values = values.to(ops.device_of(values))
-        out = ops.normalise_f64(values, self.norm)  # float64 statistics and division, one rounding to float32
-        if self.dtype != "float32":
-            if self.dtype not in _TORCH_DTYPES:
-                raise TypeError(f"data type {self.dtype!r} not understood")  # numpy's astype error
-            out = out.to(_TORCH_DTYPES[self.dtype])
-        return place(out)
+        wanted = _torch_dtype(self.dtype)
+        if wanted == torch.float32:
+            # float64 statistics and division, one rounding to float32
+            return place(ops.normalise_f64(values, self.norm))
+        # any other dtype: the float64 result converted once (float64 itself: untouched), as astype does
+        return place(ops.normalise_f64(values, self.norm, out_dtype=torch.float64).to(wanted))
 
     def compute(self, graph, nodes_name: str, **kwargs) -> torch.Tensor:
         nodes = graph[nodes_name]

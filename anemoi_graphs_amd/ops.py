@@ -58,6 +58,44 @@ def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ---------------------------------------------------------------------------------------------------
+# Ids supplied by the caller (an edge_index, a list of node ids) are bounds-checked inside the kernels that
+# follow them: an id outside its table is never dereferenced and sets a per-device error word.  numpy /
+# torch raise IndexError for such an id in the reference (edges/attributes.py:144-148,
+# processors/post_process.py:51-61); here the word is read -- and IndexError raised -- right after the call
+# when graph tensors live on the host (the results are copied there anyway), and at the next
+# ``check_ids()`` when they stay on the device (``settings.resident``: leaving that context, and
+# ``GraphCreator.create``, call it), so that a resident build takes no synchronisation for it.
+_BAD_IDS: dict[int, torch.Tensor] = {}
+
+
+def _bad_word(device: torch.device) -> torch.Tensor:
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    word = _BAD_IDS.get(index)
+    if word is None:
+        word = _BAD_IDS[index] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", index))
+    return word
+
+
+def check_ids(device: torch.device | None = None) -> None:
+    """Raise IndexError if a kernel met an id outside its table since the last check (synchronises)."""
+    words = list(_BAD_IDS.values()) if device is None else [_bad_word(device)]
+    bad = False
+    for word in words:
+        if int(word.item()):
+            word.zero_()
+            bad = True
+    if bad:
+        raise IndexError("index out of bounds: an edge_index or id array refers to a node that does not exist")
+
+
+def _ids_checked(device: torch.device) -> None:
+    from . import settings
+
+    if not settings.device_resident:
+        check_ids(device)
+
+
 def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False, return_stats: bool = False):
     """ids [Nt,k] int32 of the k nearest sources of every target, ascending distance."""
     lib = _lib.load()
@@ -208,41 +246,54 @@ def mask_ids(mask: torch.Tensor, device: torch.device) -> torch.Tensor:
 
 
 def gather_coords(x: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """out[i] = x[ids[i]] (float32 [N,2] device coordinates, int32 device ids); IndexError for an id outside x."""
     lib = _lib.load()
     dev = x.device
+    assert x.dtype == torch.float32 and x.is_contiguous() and ids.dtype == torch.int32 and ids.is_contiguous()
     out = torch.empty((ids.numel(), 2), dtype=torch.float32, device=dev)
     with _on(dev):
-        _lib.check(lib.ag_gather_coords(_ptr(x), _ptr(ids), ids.numel(), _ptr(out), _stream(dev)), "ag_gather_coords")
+        _lib.check(lib.ag_gather_coords(_ptr(x), x.shape[0], _ptr(ids), ids.numel(), _ptr(out), _ptr(_bad_word(dev)),
+                                        _stream(dev)), "ag_gather_coords")
+    _ids_checked(dev)
     return out
 
 
 def remap_ids_(values: torch.Tensor, id_map: torch.Tensor) -> torch.Tensor:
+    """values[i] = id_map[values[i]] in place; IndexError for a value outside the map."""
     lib = _lib.load()
     dev = values.device
     assert values.dtype == torch.int32 and values.is_contiguous() and id_map.dtype == torch.int32
+    assert id_map.is_contiguous() and id_map.device == dev
     with _on(dev):
-        _lib.check(lib.ag_remap_ids(_ptr(values), values.numel(), _ptr(id_map), _stream(dev)), "ag_remap_ids")
+        _lib.check(lib.ag_remap_ids(_ptr(values), values.numel(), _ptr(id_map), id_map.numel(), _ptr(_bad_word(dev)),
+                                    _stream(dev)), "ag_remap_ids")
+    _ids_checked(dev)
     return values
 
 
 def mark_ids_(mask: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """mask[ids] = 1 in place (uint8 device mask, int32 device ids)."""
+    """mask[ids] = 1 in place (uint8 device mask, int32 device ids); IndexError for an id outside the mask."""
     lib = _lib.load()
     dev = mask.device
     assert mask.dtype == torch.uint8 and mask.is_contiguous()
     ids = ids.to(device=dev, dtype=torch.int32).contiguous()
     with _on(dev):
-        _lib.check(lib.ag_mark_ids(_ptr(ids), ids.numel(), _ptr(mask), mask.numel(), _stream(dev)), "ag_mark_ids")
+        _lib.check(lib.ag_mark_ids(_ptr(ids), ids.numel(), _ptr(mask), mask.numel(), _ptr(_bad_word(dev)),
+                                   _stream(dev)), "ag_mark_ids")
+    _ids_checked(dev)
     return mask
 
 
 def invert_ids(ids: torch.Tensor, size: int) -> torch.Tensor:
-    """int32 [size] map with map[ids[j]] = j and -1 elsewhere."""
+    """int32 [size] map with map[ids[j]] = j and -1 elsewhere; IndexError for an id outside [0, size)."""
     lib = _lib.load()
     dev = ids.device
+    assert ids.dtype == torch.int32 and ids.is_contiguous()
     with _on(dev):
         out = torch.full((size,), -1, dtype=torch.int32, device=dev)
-        _lib.check(lib.ag_invert_ids(_ptr(ids), ids.numel(), _ptr(out), _stream(dev)), "ag_invert_ids")
+        _lib.check(lib.ag_invert_ids(_ptr(ids), ids.numel(), _ptr(out), size, _ptr(_bad_word(dev)), _stream(dev)),
+                   "ag_invert_ids")
+    _ids_checked(dev)
     return out
 
 
@@ -325,26 +376,36 @@ def multiscale_edges(max_resolution: int, levels: list[int], x_hops: int, rank: 
 
 
 def edge_attrs(src_x: torch.Tensor, tgt_x: torch.Tensor, edge_index: torch.Tensor, want_len: bool = True,
-               want_dir: bool = True, rotated: bool = True, len_range: bool = False):
+               want_dir: bool = True, rotated: bool = True, len_range: bool = False, dir_f64: bool = False):
     """Raw EdgeLength [E] and EdgeDirection [E,2] float32 values of an edge list.  With ``len_range``
     a third result: the device-side range of the lengths (2 words, see ag_edge_attrs_range) that
-    ``normalise_`` takes as ``value_range`` to skip its reduction pass."""
+    ``normalise_`` takes as ``value_range`` to skip its reduction pass.  ``dir_f64``: the directions as
+    float64, before the rounding to float32 (for a normalisation applied in float64, ``normalise_f64``).
+    IndexError for an edge that refers to a node outside its node set (see ``check_ids``)."""
     lib = _lib.load()
     dev = device_of(edge_index, src_x, tgt_x)
     src_x, tgt_x = coords(src_x, dev), coords(tgt_x, dev)
-    e = edge_index.to(device=dev, dtype=torch.int32).contiguous()
+    e = torch.as_tensor(edge_index).to(device=dev, dtype=torch.int32).contiguous()
+    if e.ndim != 2 or e.shape[0] != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(e.shape)}")
     num_edges = e.shape[1]
+    if num_edges and (src_x.shape[0] == 0 or tgt_x.shape[0] == 0):
+        raise IndexError("index out of bounds: edges between node sets of "
+                         f"{src_x.shape[0]} and {tgt_x.shape[0]} nodes")
+    flags = (1 if rotated else 0) | (2 if (dir_f64 and want_dir) else 0)
     with _on(dev):
         length = torch.empty(num_edges, dtype=torch.float32, device=dev) if want_len else None
-        direction = torch.empty((num_edges, 2), dtype=torch.float32, device=dev) if want_dir else None
+        direction = (torch.empty((num_edges, 2), dtype=torch.float64 if dir_f64 else torch.float32, device=dev)
+                     if want_dir else None)
         rng = (torch.empty(lib.ag_len_range_words(), dtype=torch.int32, device=dev)
                if (len_range and want_len) else None)
         _lib.check(
             lib.ag_edge_attrs_range(_ptr(src_x), src_x.shape[0], _ptr(tgt_x), tgt_x.shape[0], _ptr(e[0]), _ptr(e[1]),
-                                    num_edges, 1 if rotated else 0, _ptr(length), _ptr(direction), _ptr(rng),
+                                    num_edges, flags, _ptr(length), _ptr(direction), _ptr(rng), _ptr(_bad_word(dev)),
                                     _stream(dev)),
             "ag_edge_attrs_range",
         )
+    _ids_checked(dev)
     return (length, direction, rng) if len_range else (length, direction)
 
 
@@ -375,8 +436,9 @@ def normalise_(values: torch.Tensor, norm: str | None, invert: bool = False,
     return values
 
 
-def normalise_f64(values: torch.Tensor, norm: str | None) -> torch.Tensor:
-    """Global normalisation of a float64 device tensor, evaluated in float64 and rounded to float32."""
+def normalise_f64(values: torch.Tensor, norm: str | None, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Global normalisation of a float64 device tensor, evaluated in float64 and rounded to float32 once
+    (``out_dtype`` float64: not rounded at all)."""
     if norm not in NORMS:
         raise ValueError(
             f"Attribute normalisation \"{norm}\" is not valid. Options are: 'l1', 'l2', 'unit-max' or 'unit-std'."
@@ -385,10 +447,12 @@ def normalise_f64(values: torch.Tensor, norm: str | None) -> torch.Tensor:
     dev = values.device
     assert values.dtype == torch.float64 and values.is_contiguous()
     n = values.numel()
+    assert out_dtype in (torch.float32, torch.float64)
     with _on(dev):
-        out = torch.empty(values.shape, dtype=torch.float32, device=dev)
+        out = torch.empty(values.shape, dtype=out_dtype, device=dev)
         ws = _workspace(lib.ag_normalise_workspace_bytes(n), dev)
-        _lib.check(lib.ag_normalise_f64(_ptr(values), n, NORMS[norm], _ptr(out), _ptr(ws), ws.numel(), _stream(dev)),
+        _lib.check(lib.ag_normalise_f64(_ptr(values), n, NORMS[norm], _ptr(out), int(out_dtype == torch.float64),
+                                        _ptr(ws), ws.numel(), _stream(dev)),
                    "ag_normalise_f64")
     return out
 

@@ -11,7 +11,11 @@ device_resident: bool = False
 
 @contextlib.contextmanager
 def resident(flag: bool = True):
-    """Context manager that keeps graph tensors on the GPU between builders."""
+    """Context manager that keeps graph tensors on the GPU between builders.
+
+    Kernels that follow caller-supplied ids report an id outside its table through a device-side error word
+    instead of a synchronisation per call (``ops.check_ids``); leaving the outermost resident context reads the
+    word, so an IndexError of the reference surfaces here at the latest."""
     global device_resident
     old = device_resident
     device_resident = flag
@@ -19,3 +23,7 @@ def resident(flag: bool = True):
         yield
     finally:
         device_resident = old
+    if flag and not old:
+        from . import ops
+
+        ops.check_ids()

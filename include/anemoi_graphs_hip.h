@@ -155,13 +155,21 @@ int ag_multiscale_complete(int R, const int32_t* levels, int nlevels, const int3
  * utils.py:99-103; float32 arithmetic) and EdgeDirection.get_raw_values ->
  * directional_edge_features (edges/attributes.py:100-104, edges/directional.py:40-94; float32
  * unit vectors, float64 rotation).  Either output may be NULL.  flags: bit0 = rotated
- * direction features (luse_rotated_features).
+ * direction features (luse_rotated_features); bit1 = d_dir points to float64 [E,2] and receives the
+ * directions before their rounding to float32 (the reference normalises the float64 array and rounds
+ * afterwards, edges/attributes.py:33-40: `unit-range` needs that, see ag_normalise_f64).
  *   d_len  float32 [E]     great-circle angle in radians
- *   d_dir  float32 [E,2]
+ *   d_dir  float32 [E,2]   (float64 [E,2] with AG_ATTR_DIR_F64)
+ * Edge ids are checked against ns / nt: an id outside its node set -- numpy raises IndexError for it in the
+ * reference (edges/attributes.py:144-148) -- is not followed, the values of that edge are meaningless and
+ * *d_bad (nullable, int32, device) is set to 1.  The library never clears *d_bad: the caller zeroes it,
+ * and reads it when it next synchronises.
  */
 #define AG_ATTR_ROTATED 1
+#define AG_ATTR_DIR_F64 2
 int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt, const int32_t* d_edge_src,
-                  const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len, float* d_dir, void* stream);
+                  const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len, float* d_dir, int32_t* d_bad,
+                  void* stream);
 
 /* ag_edge_attrs that also reports the range of the lengths it wrote, so that the `unit-max` /
  * `unit-range` normalisation of EdgeLength (normalise.py:45-48: values.max(), values.min()) needs no
@@ -172,7 +180,7 @@ int ag_edge_attrs(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_
 size_t ag_len_range_words(void);
 int ag_edge_attrs_range(const float* d_src_x, int64_t ns, const float* d_tgt_x, int64_t nt, const int32_t* d_edge_src,
                         const int32_t* d_edge_tgt, int64_t E, int flags, float* d_len, float* d_dir,
-                        uint32_t* d_len_range, void* stream);
+                        uint32_t* d_len_range, int32_t* d_bad, void* stream);
 
 /* ag_normalise for norm 3 (unit-max), 4 (unit-range) or 0 from a range reported by
  * ag_edge_attrs_range: one pass, no workspace.  Same results as ag_normalise on NaN-free values. */
@@ -187,10 +195,11 @@ size_t ag_normalise_workspace_bytes(int64_t n);
 int ag_normalise(float* d_values, int64_t n, int norm, int invert, void* d_ws, size_t ws_bytes, void* stream);
 
 /* The same normalisations of a float64 array, applied in float64 and rounded to float32 once:
- * BaseNodeAttribute.post_process (nodes/attributes.py:45-52) = normalise(values).astype("float32").
- * Workspace as ag_normalise. */
-int ag_normalise_f64(const double* d_values, int64_t n, int norm, float* d_out, void* d_ws, size_t ws_bytes,
-                     void* stream);
+ * BaseNodeAttribute.post_process (nodes/attributes.py:45-52) = normalise(values).astype(dtype), and what
+ * BaseEdgeAttribute.post_process does to the float64 directions (edges/attributes.py:33-40).  d_out is
+ * float32 [n], or float64 [n] when out_f64 != 0 (dtype "float64": no rounding).  Workspace as ag_normalise. */
+int ag_normalise_f64(const double* d_values, int64_t n, int norm, void* d_out, int out_f64, void* d_ws,
+                     size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Areas of the spherical Voronoi cells of a node set.
@@ -238,21 +247,27 @@ int ag_unique_edges(int32_t* d_src, int32_t* d_tgt, int64_t E, int64_t* d_num_un
 /* ---------------------------------------------------------------------------------------
  * Node masking (edges/builder.py:162-193).
  * ag_mask_compact: ids of the true entries of a uint8 mask, ascending -> d_ids, count ->
- * *d_count (int64, device); ag_gather_coords: out[i] = x[ids[i]]; ag_remap_ids: v[i] = map[v[i]].
+ * *d_count (int64, device); ag_gather_coords: out[i] = x[ids[i]] (n_x rows in x); ag_remap_ids:
+ * v[i] = map[v[i]] (n_map entries in map).
+ * Ids that index a table (here and in ag_mark_ids / ag_invert_ids) are checked against the table's
+ * length: an id outside [0, length) -- an IndexError of numpy / torch in the reference -- is never
+ * followed (the output entry is 0 / -1, or nothing is written) and *d_bad (nullable, int32, device) is
+ * set to 1.  The library never clears *d_bad.
  */
 size_t ag_mask_compact_workspace_bytes(int64_t n);
 int ag_mask_compact(const uint8_t* d_mask, int64_t n, int32_t* d_ids, int64_t* d_count, void* d_ws,
                     size_t ws_bytes, void* stream);
-int ag_gather_coords(const float* d_x, const int32_t* d_ids, int64_t n, float* d_out, void* stream);
-int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, void* stream);
+int ag_gather_coords(const float* d_x, int64_t n_x, const int32_t* d_ids, int64_t n, float* d_out, int32_t* d_bad,
+                     void* stream);
+int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, int64_t n_map, int32_t* d_bad, void* stream);
 
 /* Post-processing of node sets (processors/post_process.py:48-61,133-149).
  * ag_mark_ids: d_mask[d_ids[i]] = 1 for every i (the mask of nodes that occur in an edge list;
  *   replaces connected_mask[edges.edge_index[r]] = True, :142-147).
  * ag_invert_ids: d_map[d_ids[j]] = j (old id -> new id for the ids kept by ag_mask_compact; with
  *   ag_remap_ids this replaces the per-edge Python dict lookup of update_edge_indices, :51-61). */
-int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, void* stream);
-int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, void* stream);
+int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, int32_t* d_bad, void* stream);
+int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, int64_t n_map, int32_t* d_bad, void* stream);
 
 /* Target column of a fixed-degree edge list: d_out[r * k + j] = r for r < rows, j < k.
  * Replaces the COO row array the reference takes from kneighbors_graph(...).tocoo()

@@ -229,7 +229,14 @@ def test_graph_descriptor_summaries(tmp_path, capsys):
     table = d.get_attribute_table()
     assert [r[:3] for r in table] == [["Node", "a", "weights"], ["Edge", "a-->b", "edge_length"], ["Edge", "a-->b", "edge_dirs"]]
     assert table[1][4:7] == [0.25, pytest.approx(1.75 / 3), 1.0]
-    torch.save(g, tmp_path / "g.pt")
+    from anemoi_graphs_amd import hetero
+
+    hetero.save_graph(g, tmp_path / "g.pt")
+    if not hetero.HAVE_TORCH_GEOMETRIC:  # plain containers: nothing in the file is executed on load
+        assert torch.load(tmp_path / "g.pt", weights_only=True)["format"] == hetero.PORTABLE_FORMAT
+    back = hetero.load_graph(tmp_path / "g.pt")
+    assert back.node_types == ["a", "b"] and back.edge_types == [("a", "to", "b")]
+    assert torch.equal(back[("a", "to", "b")].edge_index, e.edge_index) and back["a"].node_type == "LatLonNodes"
     GraphDescriptor(tmp_path / "g.pt").describe()
     out = capsys.readouterr().out
     assert "Isolated Source" in out and "Graph ready." in out

@@ -56,7 +56,9 @@ def test_graph_creator_end_to_end(device, tmp_path, resident):
                 assert value.dtype in (torch.int32, torch.float32)
                 assert value.is_cuda == resident or path.exists()
     assert path.exists()
-    loaded = torch.load(path, weights_only=False)  # a file this test wrote itself
+    from anemoi_graphs_amd.hetero import load_graph
+
+    loaded = load_graph(path)
     assert set(loaded.node_types) == {"data", "hidden"} and len(loaded.edge_types) == 3
     assert all(not v.is_cuda for n in loaded.edge_types for v in loaded[n].values() if isinstance(v, torch.Tensor))
 

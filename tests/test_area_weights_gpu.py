@@ -121,3 +121,28 @@ def test_errors_follow_scipy(device):
         SphericalAreaWeights(norm="l3").compute(g, "nodes")
     with pytest.raises(NotImplementedError):
         AreaWeights(flat=True)
+
+
+@pytest.mark.parametrize("dtype,torch_dtype", [("float64", torch.float64), ("f8", torch.float64), ("float", torch.float64),
+                                                ("float16", torch.float16), ("float32", torch.float32)])
+def test_node_attribute_dtype_keeps_float64_precision(device, dtype, torch_dtype):
+    """nodes/attributes.py:45-52 of the reference: normalise(values).astype(dtype) on the float64 values --
+    a float64 attribute is not rounded through float32, and dtype takes whatever numpy's astype takes."""
+    from anemoi_graphs_amd.hetero import HeteroData
+    from anemoi_graphs_amd.nodes.attributes import SphericalAreaWeights, UniformWeights
+    from oracle import reference_path as rp
+
+    x = rp.tri_nodes(3)[0]
+    graph = HeteroData()
+    graph["n"].x = torch.from_numpy(x)
+    got = SphericalAreaWeights(norm="unit-max", dtype=dtype).compute(graph, "n")
+    want = rp.spherical_area_weights(x, "unit-max", dtype=dtype)
+    assert got.dtype == torch_dtype and tuple(got.shape) == want.shape
+    rtol = {torch.float64: 1e-9, torch.float32: 1.2e-7, torch.float16: 1e-3}[torch_dtype]
+    np.testing.assert_allclose(got.numpy().astype(np.float64), want.astype(np.float64), rtol=rtol)
+    if torch_dtype == torch.float64:  # more than float32 precision survives
+        assert np.abs(got.numpy() - got.numpy().astype(np.float32)).max() > 0
+    u = UniformWeights(norm="l1", dtype=dtype).compute(graph, "n")
+    assert u.dtype == torch_dtype and np.array_equal(u.numpy(), rp.uniform_weights(len(x), "l1", dtype=dtype))
+    with pytest.raises(TypeError):
+        UniformWeights(dtype="not-a-dtype").compute(graph, "n")

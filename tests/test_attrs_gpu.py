@@ -20,10 +20,15 @@ def _tag(norm):
 
 
 def _attrs(src, tgt, e, device, norm=None, rotated=True, invert=False):
+    """What EdgeLength / EdgeDirection do with these arguments (anemoi_graphs_amd/edges/attributes.py)."""
+    from anemoi_graphs_amd.edges.attributes import EdgeDirection
+
+    dir_f64 = EdgeDirection(norm, rotated).wants_float64
     length, direction = ops.edge_attrs(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device),
-                                       torch.from_numpy(np.ascontiguousarray(e)).to(device), rotated=rotated)
+                                       torch.from_numpy(np.ascontiguousarray(e)).to(device), rotated=rotated,
+                                       dir_f64=dir_f64)
     length = ops.normalise_(length.reshape(-1, 1), norm, invert)
-    direction = ops.normalise_(direction, norm)
+    direction = ops.normalise_f64(direction, norm) if dir_f64 else ops.normalise_(direction, norm)
     return length.cpu().numpy(), direction.cpu().numpy()
 
 
@@ -153,3 +158,34 @@ def test_length_range_from_the_attribute_kernel(device, n_edges):
     want = ops.normalise_(plain.clone().reshape(-1, 1), "l2")
     got = ops.normalise_(length.clone().reshape(-1, 1), "l2", value_range=value_range)
     assert torch.equal(got, want)
+
+
+def test_out_of_range_edge_ids_raise_index_error(device):
+    """numpy raises IndexError for an edge that refers to a node that does not exist
+    (edges/attributes.py:144-148); the kernel never follows such an id (every launch ends normally) and the
+    host raises the same error: right after the call when graph tensors live on the host, at the end of the
+    resident context when they stay on the device."""
+    from anemoi_graphs_amd import settings
+
+    x = torch.from_numpy(grids.fibonacci_sphere(1000)).to(device)
+    good = torch.tensor([[0, 5, 999], [1, 2, 3]], dtype=torch.int32, device=device)
+    want_len, want_dir = ops.edge_attrs(x, x, good)
+    for bad_value, row in ((1000, 0), (-1, 0), (2**31 - 1, 1), (-2**31, 1)):
+        e = good.clone()
+        e[row, 1] = bad_value
+        with pytest.raises(IndexError):
+            ops.edge_attrs(x, x, e)
+        # the error word is cleared by the raise, the other edges were evaluated as usual
+        length, direction = ops.edge_attrs(x, x, good)
+        assert torch.equal(length, want_len) and torch.equal(direction, want_dir)
+    e = good.clone()
+    e[0, 2] = 5000
+    with pytest.raises(IndexError):
+        with settings.resident(True):
+            length, _ = ops.edge_attrs(x, x, e)  # deferred: no synchronisation inside a resident build
+            assert torch.equal(length[:2], want_len[:2])
+    with settings.resident(True):
+        ops.edge_attrs(x, x, good)
+    with pytest.raises(IndexError):
+        ops.edge_attrs(x[:0], x, good)
+    ops.check_ids()

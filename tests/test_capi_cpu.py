@@ -44,3 +44,20 @@ def test_argument_validation_without_gpu():
     assert lib.ag_icosphere_sizes(12, ctypes.byref(v), ctypes.byref(f), ctypes.byref(e)) == -1
     with pytest.raises(_lib.LibraryError):
         _lib.check(lib.ag_icosphere_sizes(-1, None, None, None), "ag_icosphere_sizes")
+
+
+def test_id_table_sizes_are_validated_without_gpu():
+    """The entry points that follow ids take the length of the table the ids index; sizes are validated before
+    any HIP call (the per-id check itself runs in the kernels, tests/test_edges_utils_gpu.py)."""
+    lib = _lib.load()
+    assert lib.ag_remap_ids(None, 5, None, -1, None, None) == -1 and b"negative" in lib.ag_last_error()
+    assert lib.ag_remap_ids(None, 5, None, 10, None, None) == -1 and b"null" in lib.ag_last_error()
+    assert lib.ag_gather_coords(None, -1, None, 5, None, None, None) == -1
+    assert lib.ag_invert_ids(None, 5, None, -3, None, None) == -1
+    assert lib.ag_invert_ids(None, 2**31, None, 5, None, None) == -1
+    assert lib.ag_mark_ids(None, 5, None, -1, None, None) == -1
+    assert lib.ag_remap_ids(None, 0, None, 0, None, None) == 0  # nothing to do
+    # edges between empty node sets cannot be valid
+    assert lib.ag_edge_attrs(None, 0, None, 10, None, None, 4, 1, None, None, None, None) == -1
+    assert b"4 edges" in lib.ag_last_error()
+    assert lib.ag_edge_attrs(None, 2**31, None, 10, None, None, 4, 1, None, None, None, None) == -1

@@ -39,3 +39,48 @@ def test_mask_compaction(device):
     ids = ops.mask_ids(torch.from_numpy(mask), device).cpu().numpy()
     assert np.array_equal(ids, np.where(mask[:, 0])[0])
     assert ops.mask_ids(torch.zeros(5, dtype=torch.bool), device).numel() == 0
+
+
+def test_ids_outside_their_table_raise_index_error(device):
+    """Ids are followed only inside their table: numpy / torch indexing raises IndexError in the reference
+    (edges/builder.py:176-193, processors/post_process.py:51-61,142-147); here the kernels skip such an id, end
+    normally, and the host raises."""
+    from anemoi_graphs_amd import settings
+
+    x = torch.rand((100, 2), device=device)
+    ids = torch.tensor([0, 7, 99], dtype=torch.int32, device=device)
+    assert torch.equal(ops.gather_coords(x, ids), x[ids.long()])
+    id_map = torch.arange(100, 200, dtype=torch.int32, device=device)
+    assert ops.remap_ids_(ids.clone(), id_map).tolist() == [100, 107, 199]
+    assert ops.invert_ids(ids, 100)[ids.long()].tolist() == [0, 1, 2]
+    mask = torch.zeros(100, dtype=torch.uint8, device=device)
+    assert int(ops.mark_ids_(mask, ids).sum()) == 3
+    for bad in (100, -1, 2**31 - 1):
+        wrong = torch.tensor([0, bad, 99], dtype=torch.int32, device=device)
+        with pytest.raises(IndexError):
+            ops.gather_coords(x, wrong)
+        with pytest.raises(IndexError):
+            ops.remap_ids_(wrong.clone(), id_map)
+        with pytest.raises(IndexError):
+            ops.invert_ids(wrong, 100)
+        with pytest.raises(IndexError):
+            ops.mark_ids_(torch.zeros(100, dtype=torch.uint8, device=device), wrong)
+    # resident graphs: reported when the context ends, the valid entries were processed
+    wrong = torch.tensor([3, 100, 4], dtype=torch.int32, device=device)
+    with pytest.raises(IndexError):
+        with settings.resident(True):
+            out = ops.remap_ids_(wrong.clone(), id_map)
+            assert out.tolist() == [103, -1, 104]
+    ops.check_ids()  # nothing pending
+
+
+def test_post_processor_rejects_edges_to_missing_nodes(device):
+    from anemoi_graphs_amd.hetero import HeteroData
+    from anemoi_graphs_amd.processors import RemoveUnconnectedNodes
+
+    graph = HeteroData()
+    graph["a"].x = torch.rand((10, 2))
+    graph["a"].node_type = "LatLonNodes"
+    graph[("a", "to", "a")].edge_index = torch.tensor([[0, 1, 12], [1, 2, 3]], dtype=torch.int32)
+    with pytest.raises(IndexError):
+        RemoveUnconnectedNodes("a").update_graph(graph)
