@@ -61,6 +61,7 @@ def test_attrs_golden(device, golden, case, src_key, tgt_key, prefix, ekey):
     g = golden(case)
     src, tgt, e = g[src_key].astype(np.float32), g[tgt_key].astype(np.float32), g[ekey]
     raw_dir = g[f"{prefix}dir_none"]
+    loops = (e[0] == e[1]) if src_key == tgt_key else np.zeros(e.shape[1], dtype=bool)
     for norm in NORMS:
         length, direction = _attrs(src, tgt, e, device, norm)
         _close(length, g[f"{prefix}len_{_tag(norm)}"], f"{case} {prefix}len {norm}")
@@ -68,8 +69,14 @@ def test_attrs_golden(device, golden, case, src_key, tgt_key, prefix, ekey):
             # "l1" divides by the plain sum (normalise.py:40); for direction components that cancel
             # (a symmetric grid) the divisor is rounding noise in the reference itself: not comparable
             continue
-        scale = float(np.abs(g[f"{prefix}dir_{_tag(norm)}"]).max())  # (the norms rescale the unit components)
-        _close(direction, g[f"{prefix}dir_{_tag(norm)}"], f"{case} {prefix}dir {norm}", small=DIR_SMALL * scale)
+        want_dir = g[f"{prefix}dir_{_tag(norm)}"]
+        scale = float(np.abs(want_dir).max())  # (the norms rescale the unit components)
+        _close(direction[~loops], want_dir[~loops], f"{case} {prefix}dir {norm}", small=DIR_SMALL * scale)
+        # an edge from a node to itself has no direction: the reference normalises the rounding noise of the
+        # rotated source (1e-17) after nudging it by 1e-10 (generate/transforms.py:133-140), which leaves
+        # (1, -1) / sqrt(2) with a relative noise of 1e-7 that no other implementation reproduces digit by digit
+        if loops.any():
+            np.testing.assert_allclose(direction[loops], want_dir[loops], rtol=0, atol=4e-6 * scale)
     length, _ = _attrs(src, tgt, e, device, "unit-max", invert=True)
     # stored value 1 - v, v = length / max: the tolerance is 1e-6 relative ON v (the subtraction cancels for the
     # longest edges) plus one float32 rounding of the stored value, which lies in [0, 1]
