@@ -33,6 +33,36 @@ from . import settings
 from .hetero import HeteroData
 
 
+# One host-side (gloo) group per process, shared by every builder: creating a group is a collective, so it is
+# done once, by all ranks together, and whether it is usable is decided by all ranks together.
+_HOST_GROUP: dict = {}
+
+
+def host_group(dist):
+    """The process-wide gloo group for host integers next to a device (RCCL) process group: (group, usable).
+    Created on first use by a call every rank makes; ``usable`` is the same on every rank (a rank where the
+    creation failed makes all ranks fall back to exchanging the integers on the device)."""
+    if "group" not in _HOST_GROUP:
+        group, ok = None, 1
+        try:
+            group = dist.new_group(backend="gloo")
+        except Exception:  # noqa: BLE001 - no usable host transport on this rank
+            ok = 0
+        # agree: the minimum over the ranks, through the process group that is known to work
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _HOST_GROUP["group"], _HOST_GROUP["usable"] = group, bool(flag.item())
+    return _HOST_GROUP["group"], _HOST_GROUP["usable"]
+
+
+def shutdown(dist) -> None:
+    """Release the host-side group (call before ``dist.destroy_process_group()``)."""
+    group = _HOST_GROUP.pop("group", None)
+    _HOST_GROUP.pop("usable", None)
+    if group is not None:
+        dist.destroy_process_group(group)
+
+
 class Communicator:
     """The three exchanges the sharded build needs, over ``torch.distributed`` (RCCL or gloo)."""
 
@@ -44,10 +74,10 @@ class Communicator:
         self.host_group = None
         self.sizes_on_device = False
         if dist is not None and not self.host_staged:
-            try:
-                self.host_group = dist.new_group(backend="gloo")
-            except Exception:  # noqa: BLE001 - no usable host transport: the few integers go through RCCL instead
-                self.sizes_on_device = True
+            self.host_group, usable = host_group(dist)
+            self.sizes_on_device = not usable
+            if not usable:
+                self.host_group = None
 
     def _out(self, t: torch.Tensor) -> torch.Tensor:
         return t.cpu() if self.host_staged else t

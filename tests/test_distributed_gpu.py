@@ -33,7 +33,7 @@ def _dump(g, path):
     np.savez(path, **out)
 
 
-def _worker(rank, world, port, grid, resolution, factor, out_dir, backend="gloo"):
+def _worker(rank, world, port, grid, resolution, factor, out_dir, backend="gloo", exchange=False):
     from anemoi_graphs_amd import settings
     from anemoi_graphs_amd.distributed import ShardedGraphBuilder
 
@@ -47,7 +47,8 @@ def _worker(rank, world, port, grid, resolution, factor, out_dir, backend="gloo"
         torch.cuda.set_device(0)
         data = torch.from_numpy(grids.named(grid)).to("cuda:0")
         b = ShardedGraphBuilder(data, resolution, cutoff_factor=factor, num_nearest_neighbours=3, x_hops=1, rank=rank,
-                                world_size=world, dist=dist, edge_length_norm="unit-max", edge_direction_norm="unit-std")
+                                world_size=world, dist=dist, edge_length_norm="unit-max", edge_direction_norm="unit-std",
+                                exchange_halo=exchange)
         with settings.resident(True):
             g = b.build()
         _dump(g, os.path.join(out_dir, f"rank{rank}.npz"))
@@ -55,18 +56,25 @@ def _worker(rank, world, port, grid, resolution, factor, out_dir, backend="gloo"
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grid,resolution,factor,world,backend", [
-    ("o96", 4, 0.6, 2, "gloo"), ("o320", 5, 0.6, 3, "gloo"), ("o96", 3, 3.0, 2, "gloo"),
-    ("o320", 5, 0.6, 8, "gloo"),  # as many ranks as a node has GPUs
+@pytest.mark.parametrize("grid,resolution,factor,world,backend,exchange", [
+    ("o96", 4, 0.6, 2, "gloo", False), ("o320", 5, 0.6, 3, "gloo", False), ("o96", 3, 3.0, 2, "gloo", False),
+    ("o320", 5, 0.6, 8, "gloo", False),  # as many ranks as a node has GPUs
     # RCCL with device tensors: one rank only, two ranks cannot share the one GPU of the test machine
-    ("o320", 5, 0.6, 1, "nccl"),
+    ("o320", 5, 0.6, 1, "nccl", False),
+    # coordinates treated as SHARDED (every rank searches its own band plus what its neighbours send): a
+    # radius narrower than a band -> point-to-point halo rows from the two adjacent ranks; wider than a band
+    # (factor 3.0 on a coarse mesh) -> all-gather of the bands; eight bands of O320 are one to two radii tall
+    ("o96", 4, 0.6, 2, "gloo", True), ("o320", 5, 0.6, 3, "gloo", True), ("o96", 3, 3.0, 2, "gloo", True),
+    ("o320", 5, 0.6, 8, "gloo", True), ("o96", 3, 3.0, 3, "gloo", True),
+    ("o320", 5, 0.6, 1, "nccl", True),
 ])
-def test_sharded_hip_build_equals_single(device, tmp_path, grid, resolution, factor, world, backend):
+def test_sharded_hip_build_equals_single(device, tmp_path, grid, resolution, factor, world, backend, exchange):
     from anemoi_graphs_amd import settings
     from anemoi_graphs_amd.distributed import ShardedGraphBuilder
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path), backend), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, grid, resolution, factor, str(tmp_path), backend, exchange), nprocs=world,
+             join=True)
     data = torch.from_numpy(grids.named(grid)).to(device)
     single = ShardedGraphBuilder(data, resolution, cutoff_factor=factor, num_nearest_neighbours=3, x_hops=1,
                                  edge_length_norm="unit-max", edge_direction_norm="unit-std")
