@@ -26,6 +26,7 @@ SIGNATURES = {
     "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "ag_nn_maxdist_workspace_bytes": (c_size_t, [c_int64]),
     "ag_nn_maxdist": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
+    "ag_nn_maxdist_static": (c_int, [_P, c_int64, _P, _P]),
     "ag_radius_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ag_radius_count": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, _P, c_size_t, _P]),
     "ag_radius_fill": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),

@@ -21,6 +21,8 @@
 //  * Radius query: one wave per target; lanes stride over the contiguous runs of binned sources
 //    of the covering cells (coalesced 16-byte loads), float32 chord test with a float64
 //    fallback inside the error band, ballot-compacted rows, sorted by source id in LDS.
+#include <mutex>
+
 #include "ag_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -987,6 +989,51 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
   AG_REQUIRE(n < (int64_t(1) << 31), "ag_nn_maxdist: node count must fit int32");
   AG_REQUIRE(d_pts && d_out_max && d_ws, "ag_nn_maxdist: null pointer");
   return ag_knn_run(d_pts, n, d_pts, n, 2, true, nullptr, nullptr, d_out_max, nullptr, d_ws, ws_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// ag_nn_maxdist for callers that cannot allocate: the workspace is a file-scope device array.
+// ---------------------------------------------------------------------------------------------
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends.
+// In host code the array's name is only a handle for hipGetSymbolAddress: the address that kernels, copies and
+// fills may use is the one that call returns for the current device, looked up once per device and kept.
+#define AG_STATIC_SCRATCH_BYTES (size_t(32) << 20)
+static __device__ __align__(256) unsigned char ag_static_scratch[AG_STATIC_SCRATCH_BYTES];
+
+#define AG_STATIC_MAX_DEVICES 64
+static int ag_static_scratch_address(void** out) {
+  static std::mutex lock;
+  static void* address[AG_STATIC_MAX_DEVICES] = {nullptr};
+  int device = -1;
+  AG_HIP(hipGetDevice(&device));
+  AG_REQUIRE(device >= 0 && device < AG_STATIC_MAX_DEVICES, "ag_nn_maxdist_static: device %d is not supported", device);
+  std::lock_guard<std::mutex> guard(lock);
+  if (address[device] == nullptr) {
+    void* p = nullptr;
+    AG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(ag_static_scratch)));
+    AG_REQUIRE(p != nullptr, "ag_nn_maxdist_static: no address for the scratch array on device %d", device);
+    address[device] = p;
+  }
+  *out = address[device];
+  return AG_OK;
+}
+
+extern "C" int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out_max, void* stream) {
+  AG_REQUIRE(n >= 2, "ag_nn_maxdist_static: needs at least 2 points (n=%lld)", static_cast<long long>(n));
+  AG_REQUIRE(n <= AG_NN_MAXDIST_STATIC_MAX_N,
+             "ag_nn_maxdist_static: %lld points exceed the %d the built-in scratch array holds; use ag_nn_maxdist with a "
+             "workspace", static_cast<long long>(n), AG_NN_MAXDIST_STATIC_MAX_N);
+  AG_REQUIRE(d_pts && d_out_max, "ag_nn_maxdist_static: null pointer");
+  const size_t need = ag_nn_maxdist_workspace_bytes(n);
+  AG_REQUIRE(need <= AG_STATIC_SCRATCH_BYTES, "ag_nn_maxdist_static: %zu bytes of scratch needed, %zu built in", need,
+             AG_STATIC_SCRATCH_BYTES);
+  void* scratch = nullptr;
+  const int rc = ag_static_scratch_address(&scratch);
+  if (rc) return rc;
+  // (nothing in the scratch has to be zero on entry: the kernels of the query clear the counters, queue heads and
+  // scan states they use, whatever an earlier call left there)
+  return ag_knn_run(d_pts, n, d_pts, n, 2, true, nullptr, nullptr, d_out_max, nullptr, scratch, AG_STATIC_SCRATCH_BYTES,
                     static_cast<hipStream_t>(stream));
 }
 

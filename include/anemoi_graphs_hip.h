@@ -70,6 +70,18 @@ int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k
 size_t ag_nn_maxdist_workspace_bytes(int64_t n);
 int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, size_t ws_bytes, void* stream);
 
+/* ag_nn_maxdist without a workspace argument, for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  The scratch memory is an array built into the library (32 MiB on every GPU the library runs on,
+ * held until the process ends), which bounds the input: 2 <= n <= AG_NN_MAXDIST_STATIC_MAX_N, more is refused
+ * with an error.  Nothing is allocated or freed, by the library or by a routine it calls; the first call on a
+ * device looks the array's address up (hipGetSymbolAddress), so make that call outside a capture.  Same
+ * result as ag_nn_maxdist, bit for bit.  All calls on one GPU share that GPU's array: calls that overlap on one
+ * GPU (two streams, two threads) race; successive calls on one stream do not.  Call with the device of
+ * `stream` current. */
+#define AG_NN_MAXDIST_STATIC_MAX_N 262144
+int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out_max, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Radius (cut-off) query.
  * Replaces NearestNeighbors(metric="haversine").fit(src).radius_neighbors_graph(tgt, radius)

@@ -1,0 +1,52 @@
+"""GPU: ag_nn_maxdist_static -- the reference distance through the library's built-in scratch array, for callers
+that cannot allocate -- gives the bits of ag_nn_maxdist (utils.py:61-63 of the reference), call after call on the
+same array, also when the next input is smaller than the one before."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from anemoi_graphs_amd import _lib, grids, ops
+from oracle import reference_path as rp
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(lib, x: torch.Tensor):
+    n = x.shape[0]
+    dev = x.device
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    want = torch.full((), -1.0, dtype=torch.float64, device=dev)
+    ws = torch.empty(max(lib.ag_nn_maxdist_workspace_bytes(n), 256), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ag_nn_maxdist(x.data_ptr(), n, want.data_ptr(), ws.data_ptr(), ws.numel(), stream), "ag_nn_maxdist")
+    got = torch.full((), -1.0, dtype=torch.float64, device=dev)
+    before = torch.cuda.memory_allocated(dev)
+    _lib.check(lib.ag_nn_maxdist_static(x.data_ptr(), n, got.data_ptr(), stream), "ag_nn_maxdist_static")
+    assert torch.cuda.memory_allocated(dev) == before
+    return float(got.item()), float(want.item())
+
+
+def test_static_scratch_entry_point_matches_workspace_entry_point(device):
+    lib = _lib.load()
+    torch.cuda.set_device(device)
+    hidden = ops.icosphere(7, device)[2]            # 163,842 nodes: the mesh of the headline configuration
+    big = torch.from_numpy(grids.random_sphere(262_144, seed=3)).to(device)   # the largest input it takes
+    small = torch.from_numpy(grids.random_sphere(1_000, seed=4)).to(device)
+    tiny = torch.tensor([[0.1, 0.2], [0.1, 0.2], [0.3, 0.1]], dtype=torch.float32, device=device)  # a coincident pair
+    # two calls in a row on the same array, the second with a smaller input; then smaller again, then larger
+    for x in (big, hidden.contiguous(), small, tiny, hidden.contiguous(), small):
+        got, want = _both(lib, x)
+        assert got == want and got > 0.0, (x.shape, got, want)
+    # and against the oracle (scikit-learn as the reference calls it)
+    got, _ = _both(lib, small)
+    assert got == pytest.approx(rp.grid_reference_distance(small.cpu().numpy()), rel=1e-13)
+    # sizes beyond the built-in array are refused, nothing is launched
+    out = torch.zeros((), dtype=torch.float64, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    too_many = torch.zeros((262_145, 2), dtype=torch.float32, device=device)
+    assert lib.ag_nn_maxdist_static(too_many.data_ptr(), too_many.shape[0], out.data_ptr(), stream) == -1
+    assert b"exceed" in lib.ag_last_error()
+    assert lib.ag_nn_maxdist_static(small.data_ptr(), 1, out.data_ptr(), stream) == -1
+    assert lib.ag_nn_maxdist_static(None, 10, out.data_ptr(), stream) == -1
+    torch.cuda.synchronize(device)
