@@ -24,6 +24,7 @@ SIGNATURES = {
     "ag_profile_collect": (c_int, [ctypes.c_char_p, c_size_t]),
     "ag_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_knn_within": (c_int, [_P, c_int64, _P, c_int64, c_int, c_double, _P, _P, _P, _P, c_size_t, _P]),
     "ag_nn_maxdist_workspace_bytes": (c_size_t, [c_int64]),
     "ag_nn_maxdist": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
     "ag_nn_maxdist_static": (c_int, [_P, c_int64, _P, _P]),

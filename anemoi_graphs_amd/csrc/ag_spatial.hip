@@ -236,6 +236,9 @@ struct AgKnnArgs {
   int range_len;             // 64 for dense target sets; fewer for a set queried against itself (sparse: the window grows with the span)
   const int* tcell_of;       // cell of every target, by original id
   int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
+  int bounded;               // 1: neighbours farther than rmax are not wanted (their entries become -1)
+  double rmax_window;        // bounded: the widest window stage 2 scans (rmax and a rounding pad)
+  double rmax_rdist;         // bounded: sin^2(rmax / 2), the acceptance threshold on the reduced distance
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
   unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
   long long* stats;          // [4]
@@ -677,14 +680,22 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
   }
 }
 
-// distances of the final neighbour table (only when the caller asks for them)
+// distances of the final neighbour table (when the caller asks for them) and, for a bounded search, the removal
+// of the neighbours beyond the bound: their ids become -1, their distances +infinity
 __global__ void ag_knn_dist_kernel(AgKnnArgs a) {
   const int64_t total = a.nt * a.k;
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
     const int64_t t = i / a.k;
-    const float2 tp = a.tgt[t];
-    const float2 sp = a.src[a.out_src[i]];
-    a.out_dist[i] = ag_rdist_to_dist(ag_rdist(tp.x, tp.y, sp.x, sp.y));
+    const int id = a.out_src[i];
+    double r = 2.0;  // (no neighbour: beyond every bound)
+    if (id >= 0) {
+      const float2 tp = a.tgt[t];
+      const float2 sp = a.src[id];
+      r = ag_rdist(tp.x, tp.y, sp.x, sp.y);
+    }
+    const bool keep = id >= 0 && (!a.bounded || r <= a.rmax_rdist);
+    if (!keep && id >= 0) a.out_src[i] = -1;
+    if (a.out_dist != nullptr) a.out_dist[i] = keep ? ag_rdist_to_dist(r) : __longlong_as_double(0x7ff0000000000000ll);
   }
 }
 
@@ -723,6 +734,10 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
     double R = a.rg;
     int rounds = 0;
     for (;;) {
+      // a bounded search never looks farther than the bound: the pass at the bound is the last one, and what it
+      // does not find is reported as missing
+      const bool last = a.bounded && R >= a.rmax_window;
+      if (last) R = a.rmax_window;
       const bool whole = R >= AG_PI;
       const double Rw = whole ? AG_PI : R;
       const double s = ag_sin_f64(0.5 * Rw);
@@ -730,6 +745,7 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       double prev_r = -1.0;
       int prev_i = -1;
       bool covered = true;
+      int found = 0;
       for (int j = 0; j < k; ++j) {
         double best_r = 1.0e300;
         int best_i = 0x7fffffff;
@@ -755,6 +771,7 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
         }
         prev_r = m.r;
         prev_i = m.id;
+        found = j + 1;
         if (a.self_query) {
           if (j == 1 && lane == 0 && m.r > 0.0)
             atomicMax(a.max_bits, static_cast<unsigned long long>(__double_as_longlong(m.r)));
@@ -763,6 +780,11 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
         }
       }
       if (covered || whole) break;
+      if (last) {
+        if (lane == 0 && !a.self_query)
+          for (int j = found; j < k; ++j) a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
+        break;
+      }
       R *= 2.0;
       ++rounds;
     }
@@ -886,7 +908,7 @@ static void ag_launch_stage1(const AgKnnArgs& a, hipStream_t stream) {
 
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
                       int32_t* d_out_src, double* d_out_dist, double* d_out_max, int64_t* d_stats, void* d_ws,
-                      size_t ws_bytes, hipStream_t stream) {
+                      size_t ws_bytes, hipStream_t stream, double max_dist = 0.0) {
   AgCarver sizing(nullptr);
   ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr);
   if (ws_bytes < sizing.total()) return ag_fail(AG_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sizing.total());
@@ -925,6 +947,12 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.tcell_of = w.tgt.cell_of;
   a.range_off = w.range_off;
   a.self_query = self_query ? 1 : 0;
+  a.rmax_window = max_dist * (1.0 + 1.0e-6) + 1.0e-9;
+  a.bounded = (!self_query && max_dist > 0.0 && a.rmax_window < AG_PI) ? 1 : 0;
+  {
+    const double sh = sin(0.5 * max_dist);
+    a.rmax_rdist = sh * sh;
+  }
   a.max_bits = w.max_bits;
   a.stats = reinterpret_cast<long long*>(d_stats);
 
@@ -950,7 +978,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   if (self_query) {
     AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1), stream, w.max_bits, d_out_max);
     AG_LAUNCH_CHECK();
-  } else if (d_out_dist != nullptr) {
+  } else if (d_out_dist != nullptr || a.bounded) {
     AG_KERNEL("ag_knn_dist_kernel", ag_knn_dist_kernel, dim3(ag_blocks(nt * k, 256, 16384)), dim3(256), stream, a);
     AG_LAUNCH_CHECK();
   }
@@ -974,6 +1002,20 @@ extern "C" int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_
   AG_REQUIRE(d_src && d_tgt && d_out_src && d_ws, "ag_knn: null pointer");
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double max_dist,
+                             int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes,
+                             void* stream) {
+  AG_REQUIRE(max_dist > 0.0, "ag_knn_within: the distance bound must be positive (got %g)", max_dist);
+  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_within: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(ns >= k, "ag_knn_within: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
+  AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn_within: node counts must fit int32");
+  AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn_within: output too large");
+  if (nt == 0) return AG_OK;
+  AG_REQUIRE(d_src && d_tgt && d_out_src && d_ws, "ag_knn_within: null pointer");
+  return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
+                    static_cast<hipStream_t>(stream), max_dist);
 }
 
 extern "C" size_t ag_nn_maxdist_workspace_bytes(int64_t n) {

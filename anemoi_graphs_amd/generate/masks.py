@@ -60,5 +60,9 @@ class KNNAreaMaskBuilder:
         assert self._reference is not None, "fit() or fit_coords() must be called first."
         query = ops.coords(coords_rad if isinstance(coords_rad, torch.Tensor) else np.asarray(coords_rad),
                            self._reference.device)
-        _ids, dists = ops.knn(self._reference, query, 1, return_dist=True)
+        # The mask asks whether a reference node lies within the margin, not for the nearest one wherever it is:
+        # the search stops at the margin (a vertex with nothing that close comes back with an infinite distance),
+        # so vertices far from a regional reference set cost a few empty window look-ups instead of a scan.
+        bound = float(self.margin_radius_km) / EARTH_RADIUS * (1.0 + 1.0e-9)
+        _ids, dists = ops.knn(self._reference, query, 1, return_dist=True, max_dist=bound)
         return dists[:, 0] * EARTH_RADIUS <= self.margin_radius_km

@@ -96,8 +96,10 @@ def _ids_checked(device: torch.device) -> None:
         check_ids(device)
 
 
-def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False, return_stats: bool = False):
-    """ids [Nt,k] int32 of the k nearest sources of every target, ascending distance."""
+def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False, return_stats: bool = False,
+        max_dist: float | None = None):
+    """ids [Nt,k] int32 of the k nearest sources of every target, ascending distance.  ``max_dist`` (radians):
+    neighbours farther than that are not searched for; their ids are -1 and their distances infinity."""
     lib = _lib.load()
     dev = device_of(src, tgt)
     src, tgt = coords(src, dev), coords(tgt, dev)
@@ -110,11 +112,18 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
         dist = torch.empty((nt, k), dtype=torch.float64, device=dev) if return_dist else None
         stats = torch.zeros(4, dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
-        _lib.check(
-            lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(out), _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(),
-                       _stream(dev)),
-            "ag_knn",
-        )
+        if max_dist is None:
+            _lib.check(
+                lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(out), _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(),
+                           _stream(dev)),
+                "ag_knn",
+            )
+        else:
+            _lib.check(
+                lib.ag_knn_within(_ptr(src), ns, _ptr(tgt), nt, k, float(max_dist), _ptr(out), _ptr(dist), _ptr(stats),
+                                  _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_knn_within",
+            )
     res = (out,)
     if return_dist:
         res += (dist,)

@@ -61,6 +61,14 @@ size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k);
 int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, int32_t* d_out_src,
            double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
 
+/* ag_knn that does not look beyond max_dist (radians): an entry whose neighbour would be farther than that is
+ * -1 in d_out_src and +infinity in d_out_dist.  Replaces `kneighbors(coords, n_neighbors=1)` followed by the
+ * threshold `dists * EARTH_RADIUS <= margin_radius_km` of KNNAreaMaskBuilder.get_mask (generate/masks.py:94-99):
+ * the mask only asks whether a reference node lies within the margin, so mesh vertices far from a regional
+ * reference set need no search over the whole sphere.  Workspace: ag_knn_workspace_bytes(ns, nt, k). */
+int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double max_dist,
+                  int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Grid reference distance.
  * Replaces utils.get_grid_reference_distance (utils.py:61-63): kneighbors(pts, 2) on the set

@@ -120,3 +120,35 @@ def test_node_order(device):
     got = ops.node_order(torch.as_tensor(x)).cpu().numpy()
     want = rp.coordinates_ordering_canonical(x.astype(np.float64)[:, :])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k,bound_km,n_ref,seed", [(1, 300.0, 20000, 0), (1, 30.0, 20000, 1), (3, 500.0, 5000, 2),
+                                                   (1, 2000.0, 300, 3), (2, 5.0, 50000, 4), (1, 25000.0, 1000, 5)])
+def test_knn_within_a_distance_bound(device, k, bound_km, n_ref, seed):
+    """ag_knn_within = scikit-learn's kneighbors with everything beyond the bound removed (what the area mask
+    makes of it, generate/masks.py:94-99): a regional reference set, queried from all over the sphere."""
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(seed)
+    # a cap of ~25 degrees around (40N, 10E), denser towards its centre
+    d = np.abs(rng.normal(0.0, 0.2, n_ref))
+    b = rng.uniform(0, 2 * np.pi, n_ref)
+    ref = np.stack([np.deg2rad(40.0) + d * np.cos(b), np.deg2rad(10.0) + d * np.sin(b) / np.cos(np.deg2rad(40.0))],
+                   axis=1).astype(np.float32)
+    query = rp.tri_nodes(5)[0]
+    bound = bound_km / 6371.0
+    ids, dist = ops.knn(torch.from_numpy(ref).to(device), torch.from_numpy(query).to(device), k, return_dist=True,
+                        max_dist=bound)
+    ids, dist = ids.cpu().numpy(), dist.cpu().numpy()
+    want_d, want_i = NearestNeighbors(metric="haversine").fit(ref).kneighbors(query, n_neighbors=k)
+    inside = want_d <= bound
+    edge = np.abs(want_d - bound) <= 1e-9 * bound  # (a neighbour exactly on the bound may go either way)
+    assert inside.any() and ((~inside).any() or bound_km > 20000.0)
+    assert np.all((ids >= 0) == inside | (edge & (ids >= 0)))
+    keep = inside & ~edge
+    np.testing.assert_allclose(dist[keep], want_d[keep], rtol=1e-12, atol=1e-15)
+    same = ids[keep] == want_i[keep]
+    if not same.all():  # exact distance ties may list the tied sources in another order
+        rows = np.where(keep & (ids != want_i))
+        np.testing.assert_allclose(dist[rows], want_d[rows], rtol=1e-12)
+    assert np.all(np.isinf(dist[~inside & ~edge])) and np.all(ids[~inside & ~edge] == -1)
