@@ -211,6 +211,7 @@ class ShardedGraphBuilder:
         self.data_all = data_x  # every rank is given the complete coordinate array (53 MB for O1280)
         self.data_local = data_x[lo:hi].contiguous()
         self.exchange_halo = exchange_halo
+        self.timer = PhaseTimer()
         if world_size > 1 or dist is not None:  # (a process group of one rank still takes the sharded route)
             lat = data_x[:, 0]
             if lat.numel() > 1 and bool((lat[1:] > lat[:-1]).any()):
@@ -270,12 +271,15 @@ class ShardedGraphBuilder:
     def _build_sharded(self) -> HeteroData:
         be, comm, r, W = self.backend, self.comm, self.rank, self.world
         dev = self.data_local.device
+        mark = self.timer.mark
+        mark("start")
         graph = HeteroData()
         _xyz, _faces, hidden, order, rank_map, level_edges = be.icosphere(self.resolution)
         hidden = hidden.to(dev)
         graph["hidden"].x = hidden
         graph["hidden"].node_type = "TriNodes"
         nh = hidden.shape[0]
+        mark("hidden_mesh")
 
         # ---- decoder first: my data band as targets, replicated hidden sources; only the source ids travel
         # (the target row of a k-NN edge list is 0,0,0,1,1,1,... whatever the band).  It needs nothing from
@@ -286,6 +290,7 @@ class ShardedGraphBuilder:
         dec_all = torch.empty((2, self.n_data * self.k), dtype=torch.int32, device=dev)
         dec_gather = comm.all_gather_rows_async([ids], band_sizes, out=[dec_all[0]])
         be.row_ids(self.n_data, self.k, dev, out=dec_all[1])
+        mark("decoder_search")
 
         # ---- encoder: hidden targets of my band, data sources = my band + halo
         # (band limits by binary search on the device; one host synchronisation for all of them)
@@ -311,34 +316,15 @@ class ShardedGraphBuilder:
             g_lo = s_lo
         else:
             # coordinates treated as sharded: the rows beyond my band come from the neighbouring ranks
-            if r > 0:  # the north neighbour's targets reach down to first_lat[r] - reach
-                q = (-(self.first_lat[r] - reach_t)).to(self.neg_lat.dtype)
-                n_north = torch.searchsorted(self.neg_lat, q, right=True)
-            else:
-                n_north = zero
-            if r < W - 1:  # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
-                q = (-(self.first_lat[r + 1] + reach_t)).to(self.neg_lat.dtype)
-                s_start = torch.searchsorted(self.neg_lat, q, right=False)
-            else:
-                s_start = zero + nd
-            vals = torch.stack([radius_t] + [v.reshape(()).double() for v in (h_lo, h_hi, n_north, s_start)]).tolist()
-            radius = vals[0]
-            h_lo, h_hi, n_north, s_start = (int(v) for v in vals[1:])
-            one_hop = (r == 0 or n_north < nd) and (r == W - 1 or s_start > 0)
-            sizes = comm.all_gather_sizes([int(one_hop), n_north, nd - s_start], dev)
-            if bool(sizes[:, 0].min()):
-                from_north, from_south = comm.exchange_halo(
-                    self.data_local[:n_north], self.data_local[s_start:],
-                    int(sizes[r - 1, 2]) if r > 0 else 0, int(sizes[r + 1, 1]) if r < W - 1 else 0)
-                sources = torch.cat([from_north, self.data_local, from_south], dim=0) if W > 1 else self.data_local
-                g_lo = self.d_lo - from_north.shape[0]
-            else:  # radius wider than a band: every rank takes all data rows
-                sources = comm.all_gather_rows(self.data_local)
-                g_lo = 0
+            sources, g_lo, vals = exchange_band_sources(comm, self.data_local, self.neg_lat, self.first_lat, reach_t,
+                                                        self.d_lo, extra=[radius_t, h_lo, h_hi])
+            radius, h_lo, h_hi = vals[0], int(vals[1]), int(vals[2])
         targets = hidden[h_lo:h_hi].contiguous()
+        mark("reference_distance_and_halo")
         enc = be.radius_edges(sources, targets, radius)
         enc[0] += g_lo
         enc[1] += h_lo
+        mark("encoder_search")
         enc_counts_ready = comm.all_gather_sizes_async([enc.shape[1]], dev)  # read once the processor is queued
 
         # ---- processor: replicated, while the edge lists travel
@@ -354,6 +340,7 @@ class ShardedGraphBuilder:
         graph[proc_name].edge_type = "MultiScaleEdges"
         if self.attributes:
             self._finish_attrs(graph[proc_name], *self._attrs(hidden, hidden, proc))
+        mark("processor")
 
         enc_counts = enc_counts_ready()[:, 0].tolist()
         enc_all = torch.empty((2, sum(enc_counts)), dtype=enc.dtype, device=dev)
@@ -366,10 +353,12 @@ class ShardedGraphBuilder:
             (enc_name, enc_gather, enc_all, data_all, hidden, "CutOffEdges"),
         ):
             gather()
+            mark("gather_wait_" + ("decoder" if name == dec_name else "encoder"))
             graph[name].edge_index = edge_index
             graph[name].edge_type = etype
             if self.attributes:
                 self._finish_attrs(graph[name], *self._attrs(src_x, tgt_x, edge_index))
+                mark("attributes_" + ("decoder" if name == dec_name else "encoder"))
         return graph
 
     def build(self) -> HeteroData:
@@ -377,3 +366,219 @@ class ShardedGraphBuilder:
             with settings.resident(settings.device_resident):
                 return self._build_single()
         return self._build_sharded()
+
+
+class PhaseTimer:
+    """Device-side durations of the phases of a build: an event is recorded on the current stream at every
+    ``mark``; ``milliseconds()`` (after a synchronisation) gives the time between consecutive marks, summed per
+    name over all builds since ``reset``.  Waiting for a collective is stream work too, so it shows up in the
+    phase that waits.  Off (no events) unless ``enabled``."""
+
+    def __init__(self) -> None:
+        self.enabled = False
+        self._marks: list[tuple[str, torch.cuda.Event]] = []
+
+    def reset(self) -> None:
+        self._marks = []
+
+    def mark(self, name: str) -> None:
+        if self.enabled:
+            event = torch.cuda.Event(enable_timing=True)
+            event.record()
+            self._marks.append((name, event))
+
+    def milliseconds(self) -> dict[str, float]:
+        out: dict[str, float] = {}
+        for (_, before), (name, after) in zip(self._marks, self._marks[1:]):
+            if name != "start":
+                out[name] = out.get(name, 0.0) + before.elapsed_time(after)
+        return out
+
+
+def exchange_band_sources(comm: Communicator, data_local: torch.Tensor, neg_lat: torch.Tensor, first_lat: list[float],
+                          reach_t: torch.Tensor, d_lo: int, extra: list[torch.Tensor] = ()):
+    """The data rows a rank's cut-off search needs when every rank holds only its own latitude band: the band
+    itself plus the rows of the adjacent bands within ``reach_t`` (0-dim device tensor, radians) of it, sent
+    point-to-point by the two neighbours; when the reach is wider than a neighbouring band, all bands (all-gather).
+    ``extra``: 0-dim device tensors whose values the caller wants on the host (they ride along with the one
+    synchronisation this function needs).  Returns (sources, global id of sources[0], host values of ``extra``)."""
+    r, W = comm.rank, comm.world
+    nd = data_local.shape[0]
+    dev = data_local.device
+    zero = torch.zeros((), dtype=torch.int64, device=dev)
+    if r > 0:  # the north neighbour's targets reach down to first_lat[r] - reach
+        n_north = torch.searchsorted(neg_lat, (-(first_lat[r] - reach_t)).to(neg_lat.dtype), right=True)
+    else:
+        n_north = zero
+    if r < W - 1:  # the south neighbour's targets reach up to first_lat[r+1] + reach (exclusive band top)
+        s_start = torch.searchsorted(neg_lat, (-(first_lat[r + 1] + reach_t)).to(neg_lat.dtype), right=False)
+    else:
+        s_start = zero + nd
+    vals = torch.stack([v.reshape(()).double() for v in (n_north, s_start, *extra)]).tolist()
+    n_north, s_start = int(vals[0]), int(vals[1])
+    one_hop = (r == 0 or n_north < nd) and (r == W - 1 or s_start > 0)
+    sizes = comm.all_gather_sizes([int(one_hop), n_north, nd - s_start, nd], dev)
+    if bool(sizes[:, 0].min()):
+        from_north, from_south = comm.exchange_halo(
+            data_local[:n_north], data_local[s_start:],
+            int(sizes[r - 1, 2]) if r > 0 else 0, int(sizes[r + 1, 1]) if r < W - 1 else 0)
+        sources = torch.cat([from_north, data_local, from_south], dim=0) if W > 1 else data_local
+        return sources, d_lo - from_north.shape[0], vals[2:]
+    # reach wider than a band: every rank takes all data rows
+    return comm.all_gather_rows(data_local, sizes[:, 3].tolist()), 0, vals[2:]
+
+
+class BandGraphBuilder:
+    """The graph of a data grid too large to replicate: every rank holds ONE latitude band of the data nodes
+    (``data_band``: rows ``first_id`` .. of a grid of ``n_data`` nodes ordered north -> south; the bands of the ranks
+    are consecutive) and ends with the edges of that band -- nothing but halo rows and a few scalars travels.
+
+    * hidden mesh (TriNodes of ``resolution``), its reference distance and the processor edges: replicated;
+    * encoder (CutOffEdges data -> hidden): targets = the hidden nodes of the band's latitude range, sources =
+      the band plus the rows its two neighbours send (``exchange_band_sources``);
+    * decoder (KNNEdges hidden -> data): targets = the band;
+    * edge ids are GLOBAL node ids; concatenating the ranks' encoder (decoder) lists in rank order gives the
+      list of a single-GPU build, edge for edge;
+    * attributes: evaluated per band; the global normalisation of EdgeLength (``unit-max``, ``unit-range`` or
+      none) takes the maximum / minimum over the ranks (one all-reduce of two words), so the values equal a
+      single-GPU build's bit for bit.  Directions are not normalised in this mode.
+
+    With ``dist=None`` (one rank) the band is the whole grid."""
+
+    def __init__(self, data_band: torch.Tensor, first_id: int, n_data: int, resolution: int, cutoff_factor: float = 0.6,
+                 num_nearest_neighbours: int = 3, x_hops: int = 1, rank: int = 0, world_size: int = 1, dist=None,
+                 backend=None, attributes: bool = True, edge_length_norm: str | None = "unit-max",
+                 decoder: bool = True, processor: bool = True):
+        if edge_length_norm not in (None, "unit-max", "unit-range"):
+            raise ValueError("a band build normalises edge lengths by their range only (None, unit-max, unit-range)")
+        self.backend = _hip_ops if backend is None else backend
+        self.data_band = data_band.contiguous()
+        self.first_id, self.n_data = int(first_id), int(n_data)
+        self.resolution, self.cutoff_factor, self.k, self.x_hops = resolution, cutoff_factor, num_nearest_neighbours, x_hops
+        self.rank, self.world = rank, world_size
+        self.attributes, self.len_norm = attributes, edge_length_norm
+        self.decoder, self.processor = decoder, processor
+        self.timer = PhaseTimer()
+        lat = self.data_band[:, 0]
+        if lat.numel() > 1 and bool((lat[1:] > lat[:-1]).any()):
+            raise ValueError("latitude-band sharding needs data nodes ordered north -> south")
+        self.comm = Communicator(dist, rank, world_size) if (dist is not None and world_size >= 1) else None
+        self.neg_lat = (-lat).contiguous()
+        if self.comm is not None and world_size > 1:
+            if lat.numel() == 0:
+                raise ValueError("every rank needs at least one data node")
+            # first latitude of every band: one float per rank, exchanged once (as the bits of the float32)
+            mine = int(lat[0].cpu().view(torch.int32).item())
+            bits = self.comm.all_gather_sizes([mine], lat.device)[:, 0].to(torch.int32)
+            self.first_lat = bits.view(torch.float32).double().tolist()
+            if any(a < b for a, b in zip(self.first_lat, self.first_lat[1:])):
+                raise ValueError("the bands of the ranks must follow each other north -> south")
+        else:
+            self.first_lat = [float(lat[0])] if lat.numel() else [0.0]
+
+    def _range_over_ranks(self, len_range: torch.Tensor) -> torch.Tensor:
+        """Largest and smallest length over all ranks: both words of the range are ordered like the values
+        (the second one holds the complement of the smallest length's bits), so one MAX all-reduce does it."""
+        if self.comm is None or self.world == 1:
+            return len_range
+        head = len_range[:2].clone()
+        if self.comm.host_staged:
+            host = head.cpu()
+            self.comm.dist.all_reduce(host, op=self.comm.dist.ReduceOp.MAX)
+            head = host.to(len_range.device)
+        else:
+            self.comm.dist.all_reduce(head, op=self.comm.dist.ReduceOp.MAX)
+        out = len_range.clone()
+        out[:2] = head
+        return out
+
+    def _edge_attributes(self, store, src_x, tgt_x, local_index):
+        be = self.backend
+        if be is _hip_ops:
+            length, direction, len_range = be.edge_attrs(src_x, tgt_x, local_index, len_range=True)
+            len_range = self._range_over_ranks(len_range)
+            store["edge_length"] = be.normalise_(length.reshape(-1, 1), self.len_norm, value_range=len_range)
+        else:  # (a backend without the range: the CPU tests' oracle, one rank's worth of edges at a time)
+            length, direction = be.edge_attrs(src_x, tgt_x, local_index)
+            store["edge_length"] = be.normalise_band_(length.reshape(-1, 1), self.len_norm, self.comm)
+        store["edge_dirs"] = direction
+
+    def build(self) -> HeteroData:
+        be, r, W = self.backend, self.rank, self.world
+        dev = self.data_band.device
+        mark = self.timer.mark
+        mark("start")
+        graph = HeteroData()
+        _xyz, _faces, hidden, _order, rank_map, level_edges = be.icosphere(self.resolution)
+        hidden = hidden.to(dev)
+        nh = hidden.shape[0]
+        graph["hidden"].x = hidden
+        graph["hidden"].node_type = "TriNodes"
+        graph["data"].x = self.data_band
+        graph["data"].node_type = "LatLonNodes"
+        graph["data"]["_first_id"] = self.first_id
+        mark("hidden_mesh")
+        enc_name, proc_name, dec_name = ("data", "to", "hidden"), ("hidden", "to", "hidden"), ("hidden", "to", "data")
+        for name in (enc_name, proc_name, dec_name):
+            graph[name]
+
+        # ---- decoder: needs nothing from the other ranks
+        if self.decoder:
+            nd = self.data_band.shape[0]
+            dec = torch.empty((2, nd * self.k), dtype=torch.int32, device=dev)
+            dec[0] = be.knn(hidden, self.data_band, self.k).reshape(-1)
+            be.row_ids(nd, self.k, dev, out=dec[1])
+            mark("decoder_search")
+            if self.attributes:
+                self._edge_attributes(graph[dec_name], hidden, self.data_band, dec)
+                mark("decoder_attributes")
+            dec[1] += self.first_id
+            graph[dec_name].edge_index = dec
+            graph[dec_name].edge_type = "KNNEdges"
+        else:
+            del graph._stores[dec_name]
+
+        # ---- encoder: hidden targets of my latitude range, sources = my band + halo rows
+        radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
+        reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
+        neg_hlat = (-hidden[:, 0]).contiguous()
+        zero = torch.zeros((), dtype=torch.int64, device=dev)
+        if W > 1:
+            upper = torch.tensor(-self.first_lat[r], dtype=neg_hlat.dtype, device=dev)
+            lower = torch.tensor(-self.first_lat[min(r + 1, W - 1)], dtype=neg_hlat.dtype, device=dev)
+            h_lo = torch.searchsorted(neg_hlat, upper) if r > 0 else zero
+            h_hi = torch.searchsorted(neg_hlat, lower) if r < W - 1 else zero + nh
+            sources, g_lo, vals = exchange_band_sources(self.comm, self.data_band, self.neg_lat, self.first_lat, reach_t,
+                                                        self.first_id, extra=[radius_t, h_lo, h_hi])
+            radius, h_lo, h_hi = vals[0], int(vals[1]), int(vals[2])
+        else:
+            sources, g_lo, radius, h_lo, h_hi = self.data_band, self.first_id, float(radius_t.item()), 0, nh
+        mark("halo_exchange")
+        enc = be.radius_edges(sources, hidden[h_lo:h_hi].contiguous(), radius)
+        mark("encoder_search")
+        enc[1] += h_lo
+        if self.attributes:
+            self._edge_attributes(graph[enc_name], sources, hidden, enc)
+            mark("encoder_attributes")
+        enc[0] += g_lo
+        graph[enc_name].edge_index = enc
+        graph[enc_name].edge_type = "CutOffEdges"
+        graph[enc_name]["_radius"] = radius
+
+        # ---- processor: replicated
+        if self.processor:
+            proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,
+                                       level_edges)
+            graph[proc_name].edge_index = proc
+            graph[proc_name].edge_type = "MultiScaleEdges"
+            mark("processor_search")
+            if self.attributes:
+                length, direction, len_range = (be.edge_attrs(hidden, hidden, proc, len_range=True) if be is _hip_ops
+                                                else (*be.edge_attrs(hidden, hidden, proc), None))
+                extra = {} if len_range is None else {"value_range": len_range}
+                graph[proc_name]["edge_length"] = be.normalise_(length.reshape(-1, 1).contiguous(), self.len_norm, **extra)
+                graph[proc_name]["edge_dirs"] = direction
+                mark("processor_attributes")
+        else:
+            del graph._stores[proc_name]
+        return graph

@@ -10,6 +10,10 @@ MultiScaleEdges(x_hops=1) processor hidden->hidden, KNNEdges(3) decoder hidden->
 EdgeLength + EdgeDirection for the three edge sets.  Default workload: O1280 (6,599,680 nodes)
 -> icosphere r7 (163,842 nodes), the configuration the headline metric is quoted on.
 
+``--workload stretched_1km``: a synthetic stretched grid (9 km global background, 1 km refinement disc,
+``--nodes`` nodes in all, default 5e8) against icosphere r10; every rank generates and holds only its own
+latitude band and keeps only its band's edges (``BandGraphBuilder``).
+
 Prints ONE JSON line (rank 0).  ``value`` = edges of the finished graph / wall time, in Medges/s.
 """
 from __future__ import annotations
@@ -27,8 +31,8 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from anemoi_graphs_amd import grids, ops, profiling, settings  # noqa: E402
-from anemoi_graphs_amd.distributed import ShardedGraphBuilder  # noqa: E402
+from anemoi_graphs_amd import distributed, grids, profiling, settings  # noqa: E402
+from anemoi_graphs_amd.distributed import BandGraphBuilder, ShardedGraphBuilder, band_bounds  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 WORKLOADS = {
@@ -37,7 +41,14 @@ WORKLOADS = {
     "era5_r6": ("era5", 6),
     "o96_r4": ("o96", 4),
     "o3600_r9": ("o3600", 9),  # 52 M data nodes, 2.6 M hidden nodes: a size check, not a headline
+    # stretched synthetic grid, band-sharded (every rank makes and keeps only its band): 1 km disc in a 9 km
+    # background against r10 (7 km mesh), and a small one of the same shape for rehearsals
+    "stretched_1km": ("stretched", 10),
+    "stretched_small": ("stretched", 7),
 }
+STRETCHED_DEFAULT_NODES = {"stretched_1km": 5.0e8, "stretched_small": 3.0e6}
+STRETCHED_SPACING_KM = {"stretched_1km": (9.0, 1.0), "stretched_small": (90.0, 10.0)}
+BINNINGS_DATA, BINNINGS_HIDDEN = 2.0, 2.0  # binning calls per build, by node set
 CUTOFF_FACTOR = 0.6
 KNN_K = 3
 X_HOPS = 1
@@ -60,12 +71,23 @@ def algorithmic_bytes(kernel: str, sizes: dict) -> float:
         # endpoint coordinates gathered, 4 B of length and 8 B of direction written = 36 B.
         return 36.0 * sizes["e_total"] / 3.0
     if kernel in ("ag_bin_count_kernel", "ag_bin_scatter_kernel"):
-        # five binning calls per build (two of data nodes, three of hidden nodes), averaged:
-        # count reads coordinates and writes a cell id per point; scatter reads both and writes
-        # coordinates + id in cell order
-        n = (2.0 * nd + 3.0 * nh) / 5.0
+        # binning calls of a build, averaged (the data nodes and the hidden nodes are binned twice each): count
+        # reads coordinates and writes a cell id per point; scatter reads both and writes coordinates + id in cell
+        # order
+        n = (BINNINGS_DATA * nd + BINNINGS_HIDDEN * nh) / (BINNINGS_DATA + BINNINGS_HIDDEN)
         return (12.0 if kernel.endswith("count") else 24.0) * n
     return 0.0
+
+
+def build_bytes(sizes: dict) -> float:
+    """Compulsory HBM traffic of one whole build: every node set read once per search that uses it, every edge
+    id pair written once, 36 B per edge for the attributes (see ``algorithmic_bytes``)."""
+    nd, nh = sizes["n_data"], sizes["n_hidden"]
+    decoder = 8.0 * nh + 8.0 * nd + 8.0 * sizes["e_dec"]
+    encoder = 8.0 * nh + (8.0 * nd + 8.0 * nh) + 8.0 * sizes["e_enc"]  # reference distance, then the radius query
+    nodes = 12.0 * nh  # coordinates + node order
+    processor = 4.0 * nh + 8.0 * sizes["e_proc"]
+    return decoder + encoder + nodes + processor + 36.0 * sizes["e_total"]
 
 
 def unique_bytes(kernel: str, sizes: dict):
@@ -93,8 +115,10 @@ def measured_traffic(kernel: str, workload: str):
 
 
 def cpu_baseline(data: np.ndarray, hidden: np.ndarray) -> dict:
-    """The reference's CPU path (scikit-learn, called as the reference calls it) on a bounded
-    sample of the same workload, timed on this machine's host cores."""
+    """The reference's CPU path (scikit-learn / numpy / scipy, called as the reference calls them) on a bounded
+    sample of the same workload, timed on this machine's host cores: the two searches and the two edge
+    attributes of the sampled edges.  The mesh (TriNodes, MultiScaleEdges) is not in it: the reference builds it
+    with trimesh and networkx, and trimesh is not installed."""
     from oracle import reference_path as rp
 
     n_dec = min(len(data), 150_000)
@@ -107,20 +131,47 @@ def cpu_baseline(data: np.ndarray, hidden: np.ndarray) -> dict:
     lo_h = (len(hidden) - n_enc) // 2
     e_enc = rp.radius_edges(data, hidden[lo_h:lo_h + n_enc], radius)
     t2 = time.perf_counter()
+    # EdgeLength + EdgeDirection of the sampled edges (utils.py:99-103, edges/directional.py:40-94)
+    for e, sx, tx in ((e_dec, hidden, data[lo:lo + n_dec]), (e_enc, data, hidden[lo_h:lo_h + n_enc])):
+        rp.post_process(rp.edge_lengths(sx, tx, e), "unit-max")
+        rp.post_process(rp.edge_directions(sx, tx, e), None)
+    t3 = time.perf_counter()
     edges = e_dec.shape[1] + e_enc.shape[1]
     return {
-        "value": round(edges / (t2 - t0) / 1e6, 4),
+        "value": round(edges / (t3 - t0) / 1e6, 4),
         "unit": "Medges/s",
         "cores": rp.N_JOBS,
         "host_cpus": os.cpu_count(),
         "kind": "port",
+        "kind_note": "oracle/reference_path.py: the reference's own third-party calls (scikit-learn NearestNeighbors, "
+                     "numpy, scipy Rotation) restated call for call; the reference package itself is not on this machine",
         "sample": (
             f"scikit-learn NearestNeighbors(haversine, n_jobs={rp.N_JOBS}) as the reference calls it: "
             f"KNN k={KNN_K} decoder for {n_dec} of {len(data)} data nodes ({t1 - t0:.1f} s) + reference distance "
-            f"and CutOff encoder for {n_enc} of {len(hidden)} hidden nodes over all data nodes ({t2 - t1:.1f} s); "
-            f"{edges} edges, tree builds included"
+            f"and CutOff encoder for {n_enc} of {len(hidden)} hidden nodes over all data nodes ({t2 - t1:.1f} s) + "
+            f"EdgeLength (numpy haversine) and EdgeDirection (scipy Rotation) of those {edges} edges ({t3 - t2:.1f} s, "
+            f"one thread: numpy); tree builds included"
         ),
+        "excluded": "TriNodes and MultiScaleEdges (trimesh / networkx path of the reference: trimesh is not installed), "
+                    "so the CPU number covers less work than `value` does",
+        "search_medges_per_s": round(edges / (t2 - t0) / 1e6, 4),
     }
+
+
+def host_tensor_step_ms(data_np: np.ndarray, resolution: int, steps: int = 2) -> float:
+    """One build in the package's DEFAULT mode, as the reference hands graphs around: node coordinates come as host
+    tensors, every edge list and attribute goes back to host memory (PCIe both ways inside the step)."""
+    data_host = torch.from_numpy(data_np)
+    builder = ShardedGraphBuilder(data_host, resolution, cutoff_factor=CUTOFF_FACTOR, num_nearest_neighbours=KNN_K,
+                                  x_hops=X_HOPS)
+    with settings.resident(False):
+        builder.build()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            builder.build()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def main() -> None:
@@ -129,7 +180,11 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="o1280_r7", choices=sorted(WORKLOADS))
+    ap.add_argument("--nodes", type=float, default=None, help="data nodes of a stretched workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-tensors", action="store_true", help="skip the default-mode (host tensors) timing")
+    ap.add_argument("--exchange-halo", action="store_true",
+                    help="o1280-style workloads on N > 1 ranks: treat the coordinates as sharded (halo rows travel)")
     ap.add_argument("--profile", default="dominant", choices=["dominant", "all", "off"],
                     help="which kernel launches carry HIP events inside the timed region")
     args = ap.parse_args()
@@ -170,13 +225,28 @@ def main() -> None:
         dist = None
 
     grid_name, resolution = WORKLOADS[args.workload]
-    data_np = grids.named(grid_name)
-    data = torch.from_numpy(data_np).to(device)
-
-    builder = ShardedGraphBuilder(
-        data, resolution, cutoff_factor=CUTOFF_FACTOR, num_nearest_neighbours=KNN_K, x_hops=X_HOPS,
-        rank=rank, world_size=world, dist=dist,
-    )
+    stretched = grid_name == "stretched"
+    if stretched:
+        nodes = args.nodes or STRETCHED_DEFAULT_NODES[args.workload]
+        coarse_km, fine_km = STRETCHED_SPACING_KM[args.workload]
+        grid = grids.stretched_for_nodes(nodes, coarse_km, fine_km)
+        n_data = len(grid)
+        bounds = band_bounds(n_data, world)
+        band = grid.generate(bounds[rank], bounds[rank + 1], device=device)  # this rank's rows only
+        data_np = None
+        builder = BandGraphBuilder(band, bounds[rank], n_data, resolution, cutoff_factor=CUTOFF_FACTOR,
+                                   num_nearest_neighbours=KNN_K, x_hops=X_HOPS, rank=rank, world_size=world, dist=dist)
+        workload_name = (f"stretched synthetic grid ({n_data} nodes: {coarse_km:g} km global background, {fine_km:g} km "
+                         f"inside a disc of {grid.discs[0][2] * grids.EARTH_RADIUS_KM:.0f} km radius)")
+    else:
+        data_np = grids.named(grid_name)
+        n_data = len(data_np)
+        data = torch.from_numpy(data_np).to(device)
+        builder = ShardedGraphBuilder(
+            data, resolution, cutoff_factor=CUTOFF_FACTOR, num_nearest_neighbours=KNN_K, x_hops=X_HOPS,
+            rank=rank, world_size=world, dist=dist, exchange_halo=args.exchange_halo,
+        )
+        workload_name = f"{grid_name.upper()} ({n_data} nodes)"
 
     def barrier():
         if dist is not None:
@@ -191,8 +261,12 @@ def main() -> None:
             graph = builder.build()
         barrier()
         profiling.enable(True)
+        builder.timer.enabled = world > 1 or stretched  # phases of a sharded build (one untimed step)
+        builder.timer.reset()
         graph = builder.build()  # one more untimed step, with events on every kernel launch
         barrier()
+        phase_ms = builder.timer.milliseconds() if builder.timer.enabled else None
+        builder.timer.enabled = False
         warm_ms = profiling.collect()
         # the dominant hand-written kernel among those with a stated algorithmic byte count
         probe = {"n_data": 1, "n_hidden": 1, "e_enc": 1, "e_total": 1}
@@ -208,20 +282,25 @@ def main() -> None:
         kernel_ms = profiling.collect()  # {kernel: (launches, total ms)} over the timed region
         profiling.enable(False)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     e_enc = int(graph[("data", "to", "hidden")].edge_index.shape[1])
     e_proc = int(graph[("hidden", "to", "hidden")].edge_index.shape[1])
     e_dec = int(graph[("hidden", "to", "data")].edge_index.shape[1])
+    if dist is not None:
+        stage = device if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=stage)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if stretched:  # every rank holds its band's edges: the graph is their sum (the processor is replicated)
+            counts = torch.tensor([e_enc, e_dec], dtype=torch.int64, device=stage)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            e_enc, e_dec = (int(v) for v in counts.tolist())
     e_total = e_enc + e_proc + e_dec
-    sizes = {"n_data": len(data_np), "n_hidden": int(graph["hidden"].x.shape[0]), "e_enc": e_enc,
-             "e_total": e_total}
+    sizes = {"n_data": n_data, "n_hidden": int(graph["hidden"].x.shape[0]), "e_enc": e_enc, "e_dec": e_dec,
+             "e_proc": e_proc, "e_total": e_total}
 
     if rank != 0:
         if dist is not None:
+            distributed.shutdown(dist)
             dist.destroy_process_group()
         return
 
@@ -234,22 +313,38 @@ def main() -> None:
         name = dominant
         launches, total_ms = kernel_ms[name]
         avg_ms = total_ms / max(launches, 1)
-        nbytes = algorithmic_bytes(name, sizes)
+        per_rank = dict(sizes)
+        if stretched and world > 1:  # a launch of a band build works on one rank's band
+            for key in ("n_data", "e_enc", "e_dec"):
+                per_rank[key] = sizes[key] / world
+            per_rank["e_total"] = per_rank["e_enc"] + per_rank["e_dec"] + e_proc
+        nbytes = algorithmic_bytes(name, per_rank)
         achieved = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(name, args.workload) if world == 1 else (None, None)
-        warm_steps = 1
-        strict = unique_bytes(name, sizes)
+        strict = unique_bytes(name, per_rank)
+        total_bytes = build_bytes(sizes)
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": nbytes,
-            "kernels_ms_untimed_profiled_step": {k: round(v[1] / warm_steps, 4) for k, v in sorted(warm_ms.items())},
+            # the whole build against the same roofline: its compulsory bytes over the wall time of a step
+            "build_bytes": total_bytes,
+            "build_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 5),
+            "kernels_ms_untimed_profiled_step": {k: round(v[1], 4) for k, v in sorted(warm_ms.items())},
+            "launches_per_build": int(sum(v[0] for v in warm_ms.values())),
         }
         if strict is not None and avg_ms > 0:
             # gathered coordinates counted once per node instead of once per edge
             roofline["unique_bytes_per_launch"] = strict
             roofline["frac_unique_bytes"] = round(strict / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
 
+    if stretched:
+        parallelism = "single GPU" if world == 1 else f"latitude bands x{world}, band-local input and output, halo rows only"
+    elif world == 1:
+        parallelism = "single GPU"
+    else:
+        parallelism = (f"latitude bands x{world}, " + ("sharded coordinates + halo rows" if args.exchange_halo
+                                                        else "replicated coordinates") + ", edge lists all-gathered")
     out = {
         "metric": "Medges/s, full graph build (TriNodes + CutOff encoder + MultiScale processor + KNN decoder + edge attributes)",
         "value": round(e_total / (elapsed / args.steps) / 1e6, 3),
@@ -265,21 +360,31 @@ def main() -> None:
         "dtype_note": "float64 haversine ranking behind a float32 filter, float32 attributes, int32 ids",
         "data": "synthetic",
         "config": {
-            "workload": f"{grid_name.upper()} ({sizes['n_data']} nodes) -> icosphere r{resolution} "
+            "workload": f"{workload_name} -> icosphere r{resolution} "
                         f"({sizes['n_hidden']} nodes): CutOff {CUTOFF_FACTOR} encoder {e_enc} edges, MultiScale "
                         f"x_hops={X_HOPS} processor {e_proc} edges, KNN k={KNN_K} decoder {e_dec} edges, "
                         f"EdgeLength+EdgeDirection on all",
             "edges": e_total,
-            "parallelism": "single GPU" if world == 1 else f"latitude bands x{world}",
+            "parallelism": parallelism,
         },
         "roofline": roofline,
     }
-    if not args.no_cpu_baseline and world == 1:
-        hidden_np = graph["hidden"].x.cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(data_np, hidden_np)
+    if phase_ms is not None:
+        # device time of the phases of ONE untimed, fully event-timed build on rank 0 (waits for collectives included
+        # in the phase that waits): where the time of a sharded build goes
+        out["phases_ms_rank0"] = {k: round(v, 4) for k, v in phase_ms.items()}
+    if world == 1 and not stretched:
+        if not args.no_host_tensors:
+            out["ms_per_step_host_tensors"] = round(host_tensor_step_ms(data_np, resolution), 3)
+            out["ms_per_step_host_tensors_note"] = ("the package's default mode, PCIe inside the step: coordinates from "
+                                                    "host tensors, edge lists and attributes back to host memory; never `value`")
+        if not args.no_cpu_baseline:
+            hidden_np = graph["hidden"].x.cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(data_np, hidden_np)
     sys.stdout.flush()
     os.write(line_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        distributed.shutdown(dist)
         dist.destroy_process_group()
 
 

@@ -63,3 +63,22 @@ def edge_attrs(src_x, tgt_x, edge_index, want_len=True, want_dir=True, rotated=T
 def normalise_(values, norm, invert=False):
     out = rp.post_process(_np(values), norm, invert)
     return torch.from_numpy(np.ascontiguousarray(out))
+
+
+def normalise_band_(values, norm, comm=None):
+    """Normalisation of one rank's share of an attribute by the range over ALL ranks (the CPU counterpart of the
+    range words the HIP attribute kernel reports): numpy's float32 arithmetic, normalise.py:45-48."""
+    v = _np(values).astype(np.float32)
+    if norm is None:
+        return torch.from_numpy(v)
+    lo = torch.tensor([float(v.min()) if v.size else np.inf], dtype=torch.float32)
+    hi = torch.tensor([float(v.max()) if v.size else -np.inf], dtype=torch.float32)
+    if comm is not None and comm.world > 1:
+        comm.dist.all_reduce(lo, op=comm.dist.ReduceOp.MIN)
+        comm.dist.all_reduce(hi, op=comm.dist.ReduceOp.MAX)
+    lo, hi = np.float32(lo.item()), np.float32(hi.item())
+    if norm == "unit-max":
+        return torch.from_numpy(v / hi)
+    if norm == "unit-range":
+        return torch.from_numpy((v - lo) / (hi - lo))
+    raise ValueError(norm)

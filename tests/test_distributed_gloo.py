@@ -91,3 +91,51 @@ def test_sharded_build_equals_single(tmp_path, grid, resolution, factor, world, 
 def test_band_bounds():
     assert band_bounds(10, 3) == [0, 3, 6, 10]
     assert band_bounds(6599680, 8)[-1] == 6599680
+
+
+# ---------------------------------------------------------------------------------------------------
+# band build: every rank holds only its band and keeps only its band's edges
+# ---------------------------------------------------------------------------------------------------
+def _band_worker(rank, world, port, grid, resolution, factor, out_dir):
+    from anemoi_graphs_amd.distributed import BandGraphBuilder
+    from tests import oracle_backend
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = grids.named(grid)
+        bounds = band_bounds(len(data), world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        b = BandGraphBuilder(torch.from_numpy(data[lo:hi].copy()), lo, len(data), resolution, cutoff_factor=factor,
+                             num_nearest_neighbours=3, x_hops=1, rank=rank, world_size=world, dist=dist,
+                             backend=oracle_backend, edge_length_norm="unit-max")
+        g = b.build()
+        out = {}
+        for name in (("data", "to", "hidden"), ("hidden", "to", "data"), ("hidden", "to", "hidden")):
+            key = "_".join(name)
+            out[key] = g[name].edge_index.numpy()
+            out[key + "_len"] = g[name]["edge_length"].numpy()
+            out[key + "_dir"] = g[name]["edge_dirs"].numpy()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,resolution,factor,world", [("o16", 2, 0.6, 2), ("o16", 2, 0.6, 3), ("o16", 2, 4.0, 2),
+                                                          ("reg10.0", 1, 0.6, 3)])
+def test_band_build_pieces_concatenate_to_the_single_build(tmp_path, grid, resolution, factor, world):
+    """BandGraphBuilder: the ranks' encoder and decoder lists, concatenated in rank order, are the single build's
+    lists (global ids), the attributes those of the single build with its global normalisation; the processor
+    is replicated."""
+    port = _free_port()
+    mp.spawn(_band_worker, args=(world, port, grid, resolution, factor, str(tmp_path)), nprocs=world, join=True)
+    want = _single(grid, resolution, factor)
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for key in ("data_to_hidden", "hidden_to_data"):
+        assert np.array_equal(np.concatenate([g[key] for g in got], axis=1), want[key]), key
+        np.testing.assert_allclose(np.concatenate([g[key + "_len"] for g in got]), want[key + "_len"], rtol=1e-6, atol=1e-7)
+        raw_dir = np.concatenate([g[key + "_dir"] for g in got])  # not normalised in a band build
+        np.testing.assert_allclose(raw_dir / np.std(raw_dir), want[key + "_dir"], rtol=2e-6, atol=2e-6)
+    for g in got:
+        assert np.array_equal(g["hidden_to_hidden"], want["hidden_to_hidden"])
+        np.testing.assert_allclose(g["hidden_to_hidden_len"], want["hidden_to_hidden_len"], rtol=1e-6, atol=1e-7)
