@@ -205,6 +205,52 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
 }
 
 // ---------------------------------------------------------------------------------------------
+// A binning the caller keeps: the same layout ag_bin_points carves from a workspace, in a buffer of its
+// own, so that several searches over one node set (the cut-off query that reads it as sources, the k-NN
+// query that takes it as targets) bin it once.  The buffer is described again from (n, cell) by
+// whoever uses it; nothing but device data lives in it.
+// ---------------------------------------------------------------------------------------------
+struct AgKeptBinning {
+  const void* buffer = nullptr;  // null: none
+  double cell = 0.0;
+};
+
+static int ag_kept_bands_reserve(int64_t n) { return ag_grid_bands(sqrt(4.0 * AG_PI / static_cast<double>(n > 0 ? n : 1))); }
+
+// bands of a kept binning with cells of about `cell` radians: never finer than the buffer is laid out for
+static int ag_kept_bands(int64_t n, double cell) {
+  const int nb = ag_grid_bands(cell), cap = ag_kept_bands_reserve(n);
+  return nb < cap ? nb : cap;
+}
+
+static void ag_kept_describe(const AgKeptBinning& kept, int64_t n, AgBinned* out) {
+  AgCarver c(const_cast<void*>(kept.buffer));
+  AgBinCarve bc;
+  ag_bin_carve(c, n, ag_kept_bands_reserve(n), 1, true, &bc);
+  ag_bin_describe(bc, n, ag_kept_bands(n, kept.cell), 1, out);
+}
+
+extern "C" size_t ag_binning_bytes(int64_t n) {
+  if (n < 1) return 0;
+  AgCarver c(nullptr);
+  AgBinCarve bc;
+  ag_bin_carve(c, n, ag_kept_bands_reserve(n), 1, true, &bc);
+  return c.total();
+}
+
+extern "C" int ag_binning_build(const float* d_pts, int64_t n, double cell, void* d_binning, size_t binning_bytes,
+                                void* stream) {
+  AG_REQUIRE(n >= 1 && n < (int64_t(1) << 31), "ag_binning_build: node count %lld out of range", static_cast<long long>(n));
+  AG_REQUIRE(cell > 0.0, "ag_binning_build: the cell size must be positive (got %g)", cell);
+  AG_REQUIRE(d_pts && d_binning, "ag_binning_build: null pointer");
+  if (binning_bytes < ag_binning_bytes(n)) return ag_fail(AG_ERR_WORKSPACE, "ag_binning_build: buffer too small");
+  AgCarver c(d_binning);
+  AgBinned out;
+  const int reserve = ag_kept_bands_reserve(n);
+  return ag_bin_points(c, d_pts, n, ag_kept_bands(n, cell), reserve, 1, true, static_cast<hipStream_t>(stream), &out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k-NN stage 1: target sub-cell tiles in LDS, float32 chord^2, register top-CAP (float32 only)
 // ---------------------------------------------------------------------------------------------
 #define AG_TILE 256        // staged sources per wave and pass
@@ -216,6 +262,8 @@ struct AgKnnArgs {
   const float4* spts;        // binned sources
   const int* sstart;         // source cell starts
   const int* tids;           // binned target ids
+  const float4* tpts;        // binned target records (unit vector, id) when the targets come from a kept binning, else null
+  int foreign_targets;       // 1: the target grid is a kept binning's own grid (bands and cells unrelated to the sources')
   const int* tstart;         // target cell starts
   const float2* tgt;         // target coordinates, original order
   const float2* src;         // source coordinates, original order
@@ -315,9 +363,9 @@ __device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __res
 // longitudes inside [lon_lo, lon_hi] -- and up to AG_WIN_RANGES half-open runs of binned sources that
 // hold every source within the guaranteed radius of any of them.
 // d[0] = number of runs (-1: too many, the wave enumerates them itself), d[1 + 2i], d[2 + 2i] = run i.
-#define AG_WIN_RANGES 7
+#define AG_WIN_RANGES 9
 struct __attribute__((aligned(32))) AgWindow {
-  int d[16];
+  int d[20];
   int t0, t1, band, pad;
   double lon_lo, lon_hi;
 };
@@ -401,14 +449,32 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
       w.lon_lo = col_first * wlon;
       w.lon_hi = (col_last + 1) * wlon;
       int n = 0;
-      ag_cell_window(a.sgrid, a.sstart, band, w.lon_lo, w.lon_hi, [&](int first, int last) {
+      auto keep = [&](int first, int last) {
         if (first < last && n < AG_WIN_RANGES) {
           w.d[1 + 2 * n] = first;
           w.d[2 + 2 * n] = last;
         }
         if (first < last) ++n;
-      });
-      w.d[0] = n <= AG_WIN_RANGES ? n : -1;
+      };
+      if (a.foreign_targets) {
+        // the targets' band belongs to another grid: every source cell within the guaranteed radius of the box
+        // the range of targets lies in (its band's latitudes, the longitudes of its cells)
+        const double lat_hi = AG_HALF_PI - band * a.tgrid.dlat, lat_lo = lat_hi - a.tgrid.dlat;
+        ag_for_each_range(a.sgrid, a.sstart, lat_lo, lat_hi, w.lon_lo, w.lon_hi, a.rg, keep);
+        if (n > AG_WIN_RANGES) {
+          // more runs than a descriptor holds: one run over all covered bands (their cells are contiguous
+          // in the binned array) -- a superset of the window
+          const double pad = 1.0e-7 + 1.0e-6 * a.rg;
+          const int b0 = ag_band_of(a.sgrid, lat_hi + a.rg + pad), b1 = ag_band_of(a.sgrid, lat_lo - a.rg - pad);
+          w.d[1] = a.sstart[a.sgrid.off[b0]];
+          w.d[2] = a.sstart[a.sgrid.off[b1 + 1]];
+          n = w.d[2] > w.d[1] ? 1 : 0;
+        }
+        w.d[0] = n;
+      } else {
+        ag_cell_window(a.sgrid, a.sstart, band, w.lon_lo, w.lon_hi, keep);
+        w.d[0] = n <= AG_WIN_RANGES ? n : -1;
+      }
     } else {
       w.t0 = w.t1 = 0;
     }
@@ -435,9 +501,15 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     int tid = -1;
     float3 tu = make_float3(0.f, 0.f, 0.f);
     if (active) {
-      tid = a.tids[ti];
-      const float2 tp = a.tgt[tid];
-      tu = ag_unit_vec_f32(tp.x, tp.y);
+      if (a.tpts != nullptr) {  // a kept binning holds the unit vector (rounded from float64) next to the id
+        const float4 rec = a.tpts[ti];
+        tid = __float_as_int(rec.w);
+        tu = make_float3(rec.x, rec.y, rec.z);
+      } else {
+        tid = a.tids[ti];
+        const float2 tp = a.tgt[tid];
+        tu = ag_unit_vec_f32(tp.x, tp.y);
+      }
     }
     float bd[CAP];
     int bi[CAP];
@@ -848,6 +920,7 @@ static int64_t ag_knn_windows_ub(int64_t nt, int nb, int tmult, int range_len = 
 
 struct AgKnnWs {
   AgBinned src, tgt;
+  double rg;  // angular radius around a target that its window is guaranteed to cover
   int tmult;
   int range_len;
   int* range_off;
@@ -861,17 +934,29 @@ struct AgKnnWs {
 };
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
-                          bool self_query, hipStream_t stream, AgKnnWs* w) {
-  const int nb = ag_grid_bands(ag_knn_delta(ns, k));
+                          bool self_query, hipStream_t stream, AgKnnWs* w, const AgKeptBinning& kept_tgt = AgKeptBinning()) {
+  const bool foreign = kept_tgt.buffer != nullptr;
+  // (Source cells of half the size for targets from a kept binning -- whose boxes do not line up with the source
+  // cells, so that more of a window is cells the box only touches -- were measured: fewer candidates, but more runs
+  // to stage per wave, and slower in the end: O1280 decoder 0.178 -> 0.210 ms.)
+  const int nb_std = ag_grid_bands(ag_knn_delta(ns, k));
+  const int nb = nb_std;
   const int tmult = ag_knn_tmult(nt, nb);
   int rc = ag_bin_points(c, d_src, ns, nb, nb, 1, true, stream, w ? &w->src : nullptr);
   if (rc) return rc;
+  if (w) w->rg = 0.98 * (AG_PI / nb_std);
   // A set queried against itself (the reference distance, the neighbour lists of the Voronoi cells) is binned once:
   // the targets are the binned sources, taken in ranges of 64.  (The carve is the same either way.)
   const bool same_set = w != nullptr && d_src == d_tgt && ns == nt;
-  rc = ag_bin_points(c, d_tgt, nt, nb, nb, tmult, false, stream, (w && !same_set) ? &w->tgt : nullptr);
-  if (rc) return rc;
-  if (same_set) w->tgt = w->src;
+  int nb_t = nb;
+  if (foreign) {  // the caller's binning of the targets: nothing to bin, nothing to carve
+    nb_t = ag_kept_bands(nt, kept_tgt.cell);
+    if (w) ag_kept_describe(kept_tgt, nt, &w->tgt);
+  } else {
+    rc = ag_bin_points(c, d_tgt, nt, nb, nb, tmult, false, stream, (w && !same_set) ? &w->tgt : nullptr);
+    if (rc) return rc;
+    if (same_set) w->tgt = w->src;
+  }
   const int cap = ag_knn_cap(k, self_query);
   int* queue = c.take<int>(nt);
   int* queue_count = c.take<int>(4);
@@ -879,14 +964,14 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* cand_n = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
   int* cand_t = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
   int* cand_ids = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt * cap) : nullptr;
-  const int64_t win_a = ag_knn_windows_ub(nt, nb, tmult), win_b = ag_knn_windows_ub(nt, nb, 1, AG_KNN_SELF_RANGE);
+  const int64_t win_a = ag_knn_windows_ub(nt, nb_t, foreign ? 1 : tmult), win_b = ag_knn_windows_ub(nt, nb, 1, AG_KNN_SELF_RANGE);
   AgWindow* windows = c.take<AgWindow>((win_a > win_b ? win_a : win_b) + 1);
-  int* range_off = c.take<int>(nb + 1);
+  int* range_off = c.take<int>((nb_t > nb ? nb_t : nb) + 1);
   if (w) {
     w->windows = windows;
     w->range_off = range_off;
-    w->tmult = same_set ? 1 : tmult;  // (by ranges of the source binning itself)
-    w->range_len = (same_set && !ag_knn_by_range(tmult)) ? AG_KNN_SELF_RANGE : 64;
+    w->tmult = (same_set || foreign) ? 1 : tmult;  // (by ranges of the source binning itself / of the kept binning)
+    w->range_len = (same_set && !foreign && !ag_knn_by_range(tmult)) ? AG_KNN_SELF_RANGE : 64;
     w->queue = queue;
     w->queue_count = queue_count;
     w->max_bits = max_bits;
@@ -908,13 +993,14 @@ static void ag_launch_stage1(const AgKnnArgs& a, hipStream_t stream) {
 
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
                       int32_t* d_out_src, double* d_out_dist, double* d_out_max, int64_t* d_stats, void* d_ws,
-                      size_t ws_bytes, hipStream_t stream, double max_dist = 0.0) {
+                      size_t ws_bytes, hipStream_t stream, double max_dist = 0.0,
+                      const AgKeptBinning& kept_tgt = AgKeptBinning()) {
   AgCarver sizing(nullptr);
-  ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr);
+  ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr, kept_tgt);
   if (ws_bytes < sizing.total()) return ag_fail(AG_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sizing.total());
   AgCarver c(d_ws);
   AgKnnWs w;
-  int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w);
+  int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w, kept_tgt);
   if (rc) return rc;
   AgKnnArgs a;
   a.sgrid = w.src.grid;
@@ -922,13 +1008,15 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.spts = w.src.pts;
   a.sstart = w.src.cell_start;
   a.tids = w.tgt.ids;
+  a.foreign_targets = kept_tgt.buffer != nullptr ? 1 : 0;
+  a.tpts = a.foreign_targets ? w.tgt.pts : nullptr;
   a.tstart = w.tgt.cell_start;
   a.tgt = reinterpret_cast<const float2*>(d_tgt);
   a.src = reinterpret_cast<const float2*>(d_src);
   a.ns = ns;
   a.nt = nt;
   a.k = k;
-  a.rg = 0.98 * w.src.grid.dlat;
+  a.rg = w.rg;
   {
     const double s = sin(0.5 * a.rg);
     a.rg_chord2 = static_cast<float>(4.0 * s * s * (1.0 - 1.0e-4));
@@ -1002,6 +1090,32 @@ extern "C" int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_
   AG_REQUIRE(d_src && d_tgt && d_out_src && d_ws, "ag_knn: null pointer");
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k) {
+  if (ns < 1 || nt < 1 || k < 1) return 0;
+  AgCarver c(nullptr);
+  AgKeptBinning sizing;
+  sizing.buffer = reinterpret_cast<const void*>(uintptr_t(256));  // (sizing only: never dereferenced)
+  sizing.cell = 1.0e-9;                                           // the finest grid the buffer allows: the largest carve
+  ag_knn_prepare(c, nullptr, ns, nullptr, nt, k, false, nullptr, nullptr, sizing);
+  return c.total();
+}
+
+extern "C" int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
+                             double tgt_cell, int k, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
+                             size_t ws_bytes, void* stream) {
+  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_binned: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(ns >= k, "ag_knn_binned: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
+  AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 1, "ag_knn_binned: node counts out of range");
+  AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn_binned: output too large");
+  AG_REQUIRE(tgt_cell > 0.0, "ag_knn_binned: the cell size of the binning must be the one it was built with");
+  AG_REQUIRE(d_src && d_tgt && d_tgt_binning && d_out_src && d_ws, "ag_knn_binned: null pointer");
+  AgKeptBinning kept;
+  kept.buffer = d_tgt_binning;
+  kept.cell = tgt_cell;
+  return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
+                    static_cast<hipStream_t>(stream), 0.0, kept);
 }
 
 extern "C" int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double max_dist,
@@ -1381,12 +1495,15 @@ static double ag_radius_delta(int64_t ns, double radius) {
 }
 
 static int ag_radius_prepare(AgCarver& c, const float* d_src, int64_t ns, int64_t nt, double radius, bool build,
-                             hipStream_t stream, AgRadiusWs* w) {
+                             hipStream_t stream, AgRadiusWs* w, const AgKeptBinning& kept_src = AgKeptBinning()) {
   // The carve must not depend on the radius (the workspace is sized before the radius is
   // known): the cell arrays are reserved for the finest grid any radius can ask for.
   const int nb_reserve = ag_grid_bands(sqrt(4.0 * AG_PI / static_cast<double>(ns)));
   const int nb = ag_grid_bands(ag_radius_delta(ns, radius));
-  if (w == nullptr) {
+  if (kept_src.buffer != nullptr) {
+    // the caller's binning of the sources (any cell size: the windows adapt): nothing to bin or carve here
+    if (w) ag_kept_describe(kept_src, ns, &w->src);
+  } else if (w == nullptr) {
     ag_bin_points(c, nullptr, ns, nb_reserve, nb_reserve, 1, true, stream, nullptr);
   } else if (build) {
     int rc = ag_bin_points(c, d_src, ns, nb, nb_reserve, 1, true, stream, &w->src);
@@ -1456,17 +1573,31 @@ static int ag_radius_args(const float* d_src, const float* d_tgt, int64_t nt, do
   return AG_OK;
 }
 
-extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
-                               int64_t* d_offsets, void* d_ws, size_t ws_bytes, void* stream) {
+static size_t ag_radius_ws_bytes(int64_t ns, int64_t nt, const AgKeptBinning& kept) {
+  AgCarver c(nullptr);
+  ag_radius_prepare(c, nullptr, ns, nt > 0 ? nt : 1, 0.0, false, nullptr, nullptr, kept);
+  return c.total();
+}
+
+extern "C" size_t ag_radius_binned_workspace_bytes(int64_t ns, int64_t nt) {
+  if (ns < 1 || nt < 0) return 0;
+  AgKeptBinning sizing;
+  sizing.buffer = reinterpret_cast<const void*>(uintptr_t(256));  // (sizing only: never dereferenced)
+  sizing.cell = 1.0;
+  return ag_radius_ws_bytes(ns, nt, sizing);
+}
+
+static int ag_radius_count_impl(const float* d_src, int64_t ns, const AgKeptBinning& kept, const float* d_tgt, int64_t nt,
+                                double radius, int64_t* d_offsets, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(ns >= 1 && nt >= 0, "ag_radius_count: bad sizes");
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31), "ag_radius_count: node counts must fit int32");
   AG_REQUIRE(radius >= 0.0, "ag_radius_count: negative radius");
   AG_REQUIRE(d_src && d_offsets && d_ws, "ag_radius_count: null pointer");
-  if (ws_bytes < ag_radius_workspace_bytes(ns, nt)) return ag_fail(AG_ERR_WORKSPACE, "ag_radius_count: workspace too small");
+  if (ws_bytes < ag_radius_ws_bytes(ns, nt, kept)) return ag_fail(AG_ERR_WORKSPACE, "ag_radius_count: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AgCarver c(d_ws);
   AgRadiusWs w;
-  int rc = ag_radius_prepare(c, d_src, ns, nt > 0 ? nt : 1, radius, true, s, &w);
+  int rc = ag_radius_prepare(c, d_src, ns, nt > 0 ? nt : 1, radius, true, s, &w, kept);
   if (rc) return rc;
   AgRadiusArgs a;
   ag_radius_args(d_src, d_tgt, nt, radius, w, &a);
@@ -1486,17 +1617,32 @@ extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tg
   return ag_chained_scan_i64(d_offsets, d_offsets, nt, w.scan_state, 1, s);
 }
 
-extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
-                              const int64_t* d_offsets, int64_t num_edges, int64_t max_row, int32_t* d_out_src,
-                              int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream) {
+extern "C" int ag_radius_count(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
+                               int64_t* d_offsets, void* d_ws, size_t ws_bytes, void* stream) {
+  return ag_radius_count_impl(d_src, ns, AgKeptBinning(), d_tgt, nt, radius, d_offsets, d_ws, ws_bytes, stream);
+}
+
+extern "C" int ag_radius_count_binned(const float* d_src, int64_t ns, const void* d_src_binning, double src_cell,
+                                      const float* d_tgt, int64_t nt, double radius, int64_t* d_offsets, void* d_ws,
+                                      size_t ws_bytes, void* stream) {
+  AG_REQUIRE(d_src_binning != nullptr && src_cell > 0.0, "ag_radius_count_binned: a binning and the cell size it was built with");
+  AgKeptBinning kept;
+  kept.buffer = d_src_binning;
+  kept.cell = src_cell;
+  return ag_radius_count_impl(d_src, ns, kept, d_tgt, nt, radius, d_offsets, d_ws, ws_bytes, stream);
+}
+
+static int ag_radius_fill_impl(const float* d_src, int64_t ns, const AgKeptBinning& kept, const float* d_tgt, int64_t nt,
+                               double radius, const int64_t* d_offsets, int64_t num_edges, int64_t max_row,
+                               int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(ns >= 1 && nt >= 0 && num_edges >= 0 && max_row >= 0, "ag_radius_fill: bad sizes");
   if (nt == 0 || num_edges == 0) return AG_OK;
   AG_REQUIRE(d_src && d_tgt && d_offsets && d_out_src && d_out_tgt && d_ws, "ag_radius_fill: null pointer");
-  if (ws_bytes < ag_radius_workspace_bytes(ns, nt)) return ag_fail(AG_ERR_WORKSPACE, "ag_radius_fill: workspace too small");
+  if (ws_bytes < ag_radius_ws_bytes(ns, nt, kept)) return ag_fail(AG_ERR_WORKSPACE, "ag_radius_fill: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AgCarver c(d_ws);
   AgRadiusWs w;
-  int rc = ag_radius_prepare(c, d_src, ns, nt, radius, false, s, &w);
+  int rc = ag_radius_prepare(c, d_src, ns, nt, radius, false, s, &w, kept);
   if (rc) return rc;
   AgRadiusArgs a;
   ag_radius_args(d_src, d_tgt, nt, radius, w, &a);
@@ -1526,3 +1672,26 @@ extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
+
+extern "C" int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, double radius,
+                              const int64_t* d_offsets, int64_t num_edges, int64_t max_row, int32_t* d_out_src,
+                              int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream) {
+  return ag_radius_fill_impl(d_src, ns, AgKeptBinning(), d_tgt, nt, radius, d_offsets, num_edges, max_row, d_out_src,
+                             d_out_tgt, d_ws, ws_bytes, stream);
+}
+
+extern "C" int ag_radius_fill_binned(const float* d_src, int64_t ns, const void* d_src_binning, double src_cell,
+                                     const float* d_tgt, int64_t nt, double radius, const int64_t* d_offsets,
+                                     int64_t num_edges, int64_t max_row, int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws,
+                                     size_t ws_bytes, void* stream) {
+  AG_REQUIRE(d_src_binning != nullptr && src_cell > 0.0, "ag_radius_fill_binned: a binning and the cell size it was built with");
+  AgKeptBinning kept;
+  kept.buffer = d_src_binning;
+  kept.cell = src_cell;
+  return ag_radius_fill_impl(d_src, ns, kept, d_tgt, nt, radius, d_offsets, num_edges, max_row, d_out_src, d_out_tgt, d_ws,
+                             ws_bytes, stream);
+}
+
+// the cell size ag_radius_count chooses for its own binning of ns sources and this radius: what a caller who
+// keeps the binning (ag_binning_build) passes as `cell`
+extern "C" double ag_radius_cell(int64_t ns, double radius) { return ag_radius_delta(ns > 0 ? ns : 1, radius); }

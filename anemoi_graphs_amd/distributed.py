@@ -522,27 +522,12 @@ class BandGraphBuilder:
         for name in (enc_name, proc_name, dec_name):
             graph[name]
 
-        # ---- decoder: needs nothing from the other ranks
-        if self.decoder:
-            nd = self.data_band.shape[0]
-            dec = torch.empty((2, nd * self.k), dtype=torch.int32, device=dev)
-            dec[0] = be.knn(hidden, self.data_band, self.k).reshape(-1)
-            be.row_ids(nd, self.k, dev, out=dec[1])
-            mark("decoder_search")
-            if self.attributes:
-                self._edge_attributes(graph[dec_name], hidden, self.data_band, dec)
-                mark("decoder_attributes")
-            dec[1] += self.first_id
-            graph[dec_name].edge_index = dec
-            graph[dec_name].edge_type = "KNNEdges"
-        else:
-            del graph._stores[dec_name]
-
-        # ---- encoder: hidden targets of my latitude range, sources = my band + halo rows
+        # ---- sources of the encoder: my band plus the rows my neighbours send
         radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
         reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
         neg_hlat = (-hidden[:, 0]).contiguous()
         zero = torch.zeros((), dtype=torch.int64, device=dev)
+        nd = self.data_band.shape[0]
         if W > 1:
             upper = torch.tensor(-self.first_lat[r], dtype=neg_hlat.dtype, device=dev)
             lower = torch.tensor(-self.first_lat[min(r + 1, W - 1)], dtype=neg_hlat.dtype, device=dev)
@@ -554,7 +539,38 @@ class BandGraphBuilder:
         else:
             sources, g_lo, radius, h_lo, h_hi = self.data_band, self.first_id, float(radius_t.item()), 0, nh
         mark("halo_exchange")
-        enc = be.radius_edges(sources, hidden[h_lo:h_hi].contiguous(), radius)
+        # one binning of those rows serves the encoder (as its sources) and, when they are little more than the band
+        # itself, the decoder (as its targets: the few halo rows are searched too and dropped)
+        kept = None
+        if be is _hip_ops and sources.shape[0] > 0:
+            kept = be.bin_points(sources, be.radius_cell(sources.shape[0], radius))
+            mark("binning")
+        before = self.first_id - g_lo  # halo rows in front of my band
+
+        # ---- decoder: hidden sources, my band as targets
+        if self.decoder:
+            dec = torch.empty((2, nd * self.k), dtype=torch.int32, device=dev)
+            own_cell = (40.0 / max(nh, 1)) ** 0.5 if self.k == 3 else ((2.0 * (self.k + 1) + 2.0) * 4.0 / max(nh, 1)) ** 0.5
+            if kept is not None and sources.shape[0] <= nd + nd // 8 and kept.cell <= 1.5 * own_cell:
+                ids = be.knn(hidden, None, self.k, tgt_binning=kept)
+                dec[0] = ids[before:before + nd].reshape(-1)
+            else:
+                dec[0] = be.knn(hidden, self.data_band, self.k).reshape(-1)
+            be.row_ids(nd, self.k, dev, out=dec[1])
+            mark("decoder_search")
+            if self.attributes:
+                self._edge_attributes(graph[dec_name], hidden, self.data_band, dec)
+                mark("decoder_attributes")
+            dec[1] += self.first_id
+            graph[dec_name].edge_index = dec
+            graph[dec_name].edge_type = "KNNEdges"
+        else:
+            del graph._stores[dec_name]
+
+        # ---- encoder: hidden targets of my latitude range
+        targets = hidden[h_lo:h_hi].contiguous()
+        enc = (be.radius_edges(None, targets, radius, src_binning=kept) if kept is not None
+               else be.radius_edges(sources, targets, radius))
         mark("encoder_search")
         enc[1] += h_lo
         if self.attributes:
@@ -564,6 +580,7 @@ class BandGraphBuilder:
         graph[enc_name].edge_index = enc
         graph[enc_name].edge_type = "CutOffEdges"
         graph[enc_name]["_radius"] = radius
+        del kept
 
         # ---- processor: replicated
         if self.processor:

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import logging
+import math
 from abc import ABC, abstractmethod
 
 import torch
@@ -14,6 +15,27 @@ from ..utils import concat_edges, place
 
 LOGGER = logging.getLogger(__name__)
 EARTH_RADIUS = 6371.0  # km (/root/reference/src/anemoi/graphs/__init__.py:10)
+
+
+def kept_binning(nodes: NodeStorage, cell: float | None, accept: tuple[float, float] = (0.8, 2.0)):
+    """The binning of a node set that the edge builders of a graph share, kept on the node storage as the private
+    attribute ``_binning`` (removed with the other underscore attributes when the graph is finished).
+
+    The reference fits one ball tree per builder (edges/builder.py:259-260,364-365); here a node set that serves
+    several searches -- the data nodes are the sources of the cut-off encoder and the targets of the k-NN decoder
+    -- is binned once.  ``cell`` (radians): the cell size the caller wants; a kept binning is reused when it is of
+    these coordinates and its cells are within ``accept`` times that size, else a new one replaces it.  ``cell``
+    None: whatever is kept, or None."""
+    x = torch.as_tensor(nodes.x)
+    kept = nodes["_binning"] if "_binning" in nodes else None
+    if isinstance(kept, ops.Binning) and kept.key == ops.tensor_key(x):
+        if cell is None or accept[0] * cell <= kept.cell <= accept[1] * cell:
+            return kept
+    if cell is None:
+        return None
+    kept = ops.bin_points(x, cell)
+    nodes["_binning"] = kept
+    return kept
 
 
 class BaseEdgeBuilder(ABC):
@@ -117,13 +139,21 @@ class KNNEdges(BaseEdgeBuilder, NodeMaskingMixin):
         self.num_nearest_neighbours = num_nearest_neighbours
 
     def get_adjacency_matrix(self, source_nodes: NodeStorage, target_nodes: NodeStorage) -> torch.Tensor:
-        source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
         assert self.num_nearest_neighbours is not None, "number of neighbors required for knn encoder"
         LOGGER.info(
             "Using KNN-Edges (with %d nearest neighbours) between %s and %s.",
             self.num_nearest_neighbours, self.source_name, self.target_name,
         )
         k = self.num_nearest_neighbours
+        if self.source_mask_attr_name is None and self.target_mask_attr_name is None:
+            # targets that another builder of this graph already binned (the data nodes, as the sources of a
+            # cut-off encoder) are taken in that order, if its cells are not coarser than this search's own
+            kept = kept_binning(target_nodes, None)
+            n_src = int(torch.as_tensor(source_nodes.x).shape[0])
+            own_cell = math.sqrt((2.0 * (k + 1) + 2.0) * 4.0 / max(n_src, 1))
+            if kept is not None and kept.cell <= 1.5 * own_cell:
+                return ops.knn_edges(ops.coords(source_nodes.x, kept.x.device), None, k, tgt_binning=kept)
+        source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
         edge_index = ops.knn_edges(source_coords, target_coords, k)  # per target: ascending distance
         return self.undo_masking(edge_index, source_nodes, target_nodes)
 
@@ -158,11 +188,17 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
         return super().prepare_node_data(graph)
 
     def get_adjacency_matrix(self, source_nodes: NodeStorage, target_nodes: NodeStorage) -> torch.Tensor:
-        source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
         LOGGER.info(
             "Using CutOff-Edges (with radius = %.1f km) between %s and %s.",
             self.radius * EARTH_RADIUS, self.source_name, self.target_name,
         )
+        if self.source_mask_attr_name is None and self.target_mask_attr_name is None:
+            # the sources are binned into a buffer that stays with the node set, for the builders that follow
+            n_src = int(torch.as_tensor(source_nodes.x).shape[0])
+            if n_src > 0:
+                kept = kept_binning(source_nodes, ops.radius_cell(n_src, self.radius))
+                return ops.radius_edges(None, ops.coords(target_nodes.x, kept.x.device), self.radius, src_binning=kept)
+        source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
         edge_index = ops.radius_edges(source_coords, target_coords, self.radius)
         return self.undo_masking(edge_index, source_nodes, target_nodes)
 

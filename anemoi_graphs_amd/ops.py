@@ -96,13 +96,52 @@ def _ids_checked(device: torch.device) -> None:
         check_ids(device)
 
 
+class Binning:
+    """A node set binned once for several searches (``ag_binning_build``): the device coordinates, the buffer
+    that holds the binned records and cell tables, and the cell size they were built with."""
+
+    def __init__(self, x: torch.Tensor, buffer: torch.Tensor, cell: float, key) -> None:
+        self.x, self.buffer, self.cell, self.key = x, buffer, float(cell), key
+
+    @property
+    def n(self) -> int:
+        return int(self.x.shape[0])
+
+
+def tensor_key(t: torch.Tensor):
+    """Identity of a tensor's contents as far as it can be told without reading them."""
+    return (t.data_ptr(), tuple(t.shape), t.dtype, str(t.device), t._version)
+
+
+def radius_cell(ns: int, radius: float) -> float:
+    """Cell size a cut-off search of this radius over ``ns`` sources works best with."""
+    return float(_lib.load().ag_radius_cell(int(ns), float(radius)))
+
+
+def bin_points(x: torch.Tensor, cell: float, device: torch.device | None = None) -> Binning:
+    """Bin a node set (any tensor-like [N,2]) into cells of about ``cell`` radians, to be handed to
+    ``radius_edges(src_binning=...)`` as its sources and ``knn`` / ``knn_edges(tgt_binning=...)`` as its targets."""
+    lib = _lib.load()
+    src = torch.as_tensor(x)
+    dev = device_of(src) if device is None else device
+    xd = coords(src, dev)
+    n = xd.shape[0]
+    if n < 1:
+        raise ValueError("cannot bin an empty node set")
+    with _on(dev):
+        buf = torch.empty(lib.ag_binning_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ag_binning_build(_ptr(xd), n, float(cell), _ptr(buf), buf.numel(), _stream(dev)), "ag_binning_build")
+    return Binning(xd, buf, cell, tensor_key(src))
+
+
 def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False, return_stats: bool = False,
-        max_dist: float | None = None):
+        max_dist: float | None = None, tgt_binning: Binning | None = None):
     """ids [Nt,k] int32 of the k nearest sources of every target, ascending distance.  ``max_dist`` (radians):
     neighbours farther than that are not searched for; their ids are -1 and their distances infinity."""
     lib = _lib.load()
-    dev = device_of(src, tgt)
-    src, tgt = coords(src, dev), coords(tgt, dev)
+    dev = device_of(src, tgt) if tgt_binning is None else tgt_binning.x.device
+    src = coords(src, dev)
+    tgt = coords(tgt, dev) if tgt_binning is None else tgt_binning.x
     ns, nt = src.shape[0], tgt.shape[0]
     if k > ns:
         # what scikit-learn raises in the reference (sklearn/neighbors/_base.py, kneighbors)
@@ -111,6 +150,15 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
         out = torch.empty((nt, k), dtype=torch.int32, device=dev)
         dist = torch.empty((nt, k), dtype=torch.float64, device=dev) if return_dist else None
         stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        if tgt_binning is not None and max_dist is None and nt > 0:
+            ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k), dev)
+            _lib.check(
+                lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k, _ptr(out),
+                                  _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_knn_binned",
+            )
+            res = (out,) + ((dist,) if return_dist else ()) + ((stats,) if return_stats else ())
+            return res[0] if len(res) == 1 else res
         ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
         if max_dist is None:
             _lib.check(
@@ -132,23 +180,32 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
     return res[0] if len(res) == 1 else res
 
 
-def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int) -> torch.Tensor:
+def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning | None = None) -> torch.Tensor:
     """edge_index [2, Nt*k] int32 of the k-NN graph: row 0 the k nearest sources of every target
-    (ascending distance), row 1 the target id."""
+    (ascending distance), row 1 the target id.  ``tgt_binning``: a kept binning of the targets."""
     lib = _lib.load()
-    dev = device_of(src, tgt)
-    src, tgt = coords(src, dev), coords(tgt, dev)
+    dev = device_of(src, tgt) if tgt_binning is None else tgt_binning.x.device
+    src = coords(src, dev)
+    tgt = coords(tgt, dev) if tgt_binning is None else tgt_binning.x
     ns, nt = src.shape[0], tgt.shape[0]
     if k > ns:
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ns}")
     with _on(dev):
         edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=dev)
-        ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
-        _lib.check(
-            lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(edge_index[0]), None, None, _ptr(ws), ws.numel(),
-                       _stream(dev)),
-            "ag_knn",
-        )
+        if tgt_binning is not None and nt > 0:
+            ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k), dev)
+            _lib.check(
+                lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k,
+                                  _ptr(edge_index[0]), None, None, _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_knn_binned",
+            )
+        else:
+            ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
+            _lib.check(
+                lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(edge_index[0]), None, None, _ptr(ws), ws.numel(),
+                           _stream(dev)),
+                "ag_knn",
+            )
         _lib.check(lib.ag_fill_row_ids(_ptr(edge_index[1]), nt, k, _stream(dev)), "ag_fill_row_ids")
     return edge_index
 
@@ -181,27 +238,44 @@ def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float) -> torch.Tensor:
-    """edge_index [2,E] int32 (row 0 source id, row 1 target id), sorted by (target, source)."""
+def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, src_binning: Binning | None = None) -> torch.Tensor:
+    """edge_index [2,E] int32 (row 0 source id, row 1 target id), sorted by (target, source).
+    ``src_binning``: a kept binning of the sources (``bin_points``), used instead of binning them here."""
     lib = _lib.load()
-    dev = device_of(src, tgt)
-    src, tgt = coords(src, dev), coords(tgt, dev)
+    dev = device_of(src, tgt) if src_binning is None else src_binning.x.device
+    src = coords(src, dev) if src_binning is None else src_binning.x
+    tgt = coords(tgt, dev)
     ns, nt = src.shape[0], tgt.shape[0]
     radius = float(radius)
     with _on(dev):
         offsets = torch.empty(nt + 2, dtype=torch.int64, device=dev)
-        ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
-        _lib.check(
-            lib.ag_radius_count(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), _ptr(ws), ws.numel(), _stream(dev)),
-            "ag_radius_count",
-        )
+        if src_binning is None:
+            ws = _workspace(lib.ag_radius_workspace_bytes(ns, nt), dev)
+            _lib.check(
+                lib.ag_radius_count(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_radius_count",
+            )
+        else:
+            ws = _workspace(lib.ag_radius_binned_workspace_bytes(ns, nt), dev)
+            _lib.check(
+                lib.ag_radius_count_binned(_ptr(src), ns, _ptr(src_binning.buffer), src_binning.cell, _ptr(tgt), nt, radius,
+                                           _ptr(offsets), _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_radius_count_binned",
+            )
         num_edges, max_row = offsets[nt:].tolist()  # the one host synchronisation: output size, longest row
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
-        if num_edges:
+        if num_edges and src_binning is None:
             _lib.check(
                 lib.ag_radius_fill(_ptr(src), ns, _ptr(tgt), nt, radius, _ptr(offsets), num_edges, max_row,
                                    _ptr(edge_index[0]), _ptr(edge_index[1]), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_radius_fill",
+            )
+        elif num_edges:
+            _lib.check(
+                lib.ag_radius_fill_binned(_ptr(src), ns, _ptr(src_binning.buffer), src_binning.cell, _ptr(tgt), nt, radius,
+                                          _ptr(offsets), num_edges, max_row, _ptr(edge_index[0]), _ptr(edge_index[1]),
+                                          _ptr(ws), ws.numel(), _stream(dev)),
+                "ag_radius_fill_binned",
             )
     return edge_index
 

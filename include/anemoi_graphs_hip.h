@@ -112,6 +112,34 @@ int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t n
                    int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * A binning the caller keeps (no counterpart in the reference, whose every builder fits a ball tree of its
+ * own: edges/builder.py:259-260,364-365).  One node set often serves several searches of a graph -- the data
+ * nodes are the sources of the cut-off encoder and the targets of the k-NN decoder -- and each of the entry
+ * points above bins its inputs inside its workspace.  ag_binning_build bins a node set once into a caller-owned
+ * buffer of ag_binning_bytes(n) bytes, with cells of about `cell` radians (for a cut-off search:
+ * ag_radius_cell(ns, radius), the size ag_radius_count would choose itself); the *_binned entry points take the
+ * buffer together with the SAME n and cell and skip their own binning of that set:
+ *  - ag_radius_count_binned / ag_radius_fill_binned: the binning of the SOURCES (any cell size works; the
+ *    search is fastest with ag_radius_cell).  Workspace: ag_radius_binned_workspace_bytes(ns, nt).
+ *  - ag_knn_binned: the binning of the TARGETS (their order and unit vectors are taken from it).  Workspace:
+ *    ag_knn_binned_workspace_bytes(ns, nt, k).
+ * Results are identical to the entry points without a kept binning.  The buffer must stay untouched while
+ * a search that was given it is in flight. */
+size_t ag_binning_bytes(int64_t n);
+double ag_radius_cell(int64_t ns, double radius);
+int ag_binning_build(const float* d_pts, int64_t n, double cell, void* d_binning, size_t binning_bytes, void* stream);
+size_t ag_radius_binned_workspace_bytes(int64_t ns, int64_t nt);
+int ag_radius_count_binned(const float* d_src, int64_t ns, const void* d_src_binning, double src_cell, const float* d_tgt,
+                           int64_t nt, double radius, int64_t* d_offsets, void* d_ws, size_t ws_bytes, void* stream);
+int ag_radius_fill_binned(const float* d_src, int64_t ns, const void* d_src_binning, double src_cell, const float* d_tgt,
+                          int64_t nt, double radius, const int64_t* d_offsets, int64_t num_edges, int64_t max_row,
+                          int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream);
+size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k);
+int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
+                  double tgt_cell, int k, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
+                  size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Icosphere nodes.
  * Replaces trimesh.creation.icosphere(subdivisions=R, radius=1.0) + cartesian_to_latlon_rad +
  * get_coordinates_ordering (generate/tri_icosahedron.py:47-49,121-122; generate/transforms.py:

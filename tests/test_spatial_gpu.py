@@ -170,3 +170,82 @@ def test_radius_o1280_to_r4(device):
     radius = rp.cutoff_radius(hidden, 0.6)
     res = _radius_case(data, hidden, radius, device)
     print(res)
+
+
+def _clustered(n, seed):
+    rng = np.random.default_rng(seed)
+    half = n // 2
+    lat = np.concatenate([np.arcsin(rng.uniform(-1, 1, half)), np.clip(rng.normal(1.2, 0.15, n - half), -1.57, 1.57)])
+    lon = np.concatenate([rng.uniform(0, 2 * np.pi, half), rng.normal(0.1, 0.3, n - half) % (2 * np.pi)])
+    return np.stack([lat, lon], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_src,n_tgt,seed", [(200_000, 3_000, 0), (5_000, 5_000, 1), (300, 40, 2), (50_000, 1, 3)])
+@pytest.mark.parametrize("scale", [1.0, 0.3, 4.0, 1e-6, 1e6])
+def test_radius_query_on_a_kept_binning(device, n_src, n_tgt, seed, scale):
+    """The cut-off query gives the same edge list whether it bins its sources itself or is handed a binning the
+    caller keeps, whatever the cell size of that binning (ag_radius_count_binned / ag_radius_fill_binned)."""
+    src, tgt = _clustered(n_src, seed), grids.random_sphere(n_tgt, seed=100 + seed)
+    radius = 2.5 * np.sqrt(4 * np.pi / n_src)
+    s, t = torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device)
+    want = ops.radius_edges(s, t, radius)
+    kept = ops.bin_points(s, scale * ops.radius_cell(n_src, radius))
+    got = ops.radius_edges(None, t, radius, src_binning=kept)
+    assert torch.equal(got, want)
+    again = ops.radius_edges(None, t[: max(1, n_tgt // 2)], 0.5 * radius, src_binning=kept)  # the binning is not consumed
+    assert torch.equal(again, ops.radius_edges(s, t[: max(1, n_tgt // 2)], 0.5 * radius))
+
+
+@pytest.mark.parametrize("n_src,n_tgt,k,seed", [(40_000, 900_000, 3, 0), (2_000, 50_000, 1, 1), (2_000, 50_000, 8, 2),
+                                                (60_000, 60_000, 3, 3), (12, 5_000, 3, 4), (100_000, 700, 20, 5)])
+@pytest.mark.parametrize("scale", [1.0, 0.25, 3.0, 1e-6, 50.0])
+def test_knn_with_targets_from_a_kept_binning(device, n_src, n_tgt, k, seed, scale):
+    """k-NN with the targets taken from a kept binning (their order, their unit vectors) -- any cell size, dense and
+    sparse target sets -- returns the rows of the plain query (ag_knn_binned); both equal scikit-learn's."""
+    src, tgt = grids.random_sphere(n_src, seed=seed), _clustered(n_tgt, 50 + seed)
+    s, t = torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device)
+    want = ops.knn_edges(s, t, k)
+    cell = scale * np.sqrt(4 * np.pi / n_tgt) * 4.0
+    kept = ops.bin_points(t, cell)
+    got = ops.knn_edges(s, None, k, tgt_binning=kept)
+    assert torch.equal(got, want)
+    ids, dist = ops.knn(s, None, k, return_dist=True, tgt_binning=kept)
+    ids2, dist2 = ops.knn(s, t, k, return_dist=True)
+    assert torch.equal(ids, ids2) and torch.equal(dist, dist2)
+    if n_tgt <= 60_000:
+        rows = h.knn_rows(rp.knn_edges(src, tgt, k), n_tgt, k)
+        assert h.compare_knn(src, tgt, ids.cpu().numpy(), rows)["bad_rows"] == []
+
+
+def test_builders_share_one_binning_of_the_data_nodes(device):
+    """CutOffEdges leaves its binning of the source nodes on the node storage; KNNEdges towards those nodes takes
+    its targets from it; the graph is the one two independent builders make, and clean() drops the binning."""
+    from anemoi_graphs_amd import settings
+    from anemoi_graphs_amd.create import GraphCreator
+    from anemoi_graphs_amd.edges import CutOffEdges, KNNEdges
+    from anemoi_graphs_amd.hetero import HeteroData
+    from anemoi_graphs_amd.nodes import TriNodes
+
+    data = grids.octahedral(200)
+    for resident in (True, False):
+        with settings.resident(resident):
+            graph = HeteroData()
+            graph["data"].x = torch.from_numpy(data).to(device) if resident else torch.from_numpy(data)
+            graph["data"].node_type = "LatLonNodes"
+            graph = TriNodes(5, "hidden").update_graph(graph, {})
+            graph = CutOffEdges("data", "hidden", 0.6).update_graph(graph)
+            kept = graph["data"]["_binning"]
+            assert isinstance(kept, ops.Binning) and kept.n == len(data)
+            graph = KNNEdges("hidden", "data", 3).update_graph(graph)
+            assert graph["data"]["_binning"] is kept
+            hidden = graph["hidden"].x
+            want_enc = ops.radius_edges(torch.from_numpy(data).to(device), hidden.to(device),
+                                        0.6 * float(ops.nn_maxdist(hidden).item()))
+            want_dec = ops.knn_edges(hidden.to(device), torch.from_numpy(data).to(device), 3)
+            assert torch.equal(graph[("data", "to", "hidden")].edge_index.to(device), want_enc)
+            assert torch.equal(graph[("hidden", "to", "data")].edge_index.to(device), want_dec)
+            # new coordinates under the same name: the kept binning is not trusted
+            graph["data"].x = graph["data"].x.clone()
+            graph = KNNEdges("hidden", "data", 3).update_graph(graph)
+            graph = GraphCreator({"nodes": {}, "edges": []}).clean(graph)
+            assert "_binning" not in graph["data"]
