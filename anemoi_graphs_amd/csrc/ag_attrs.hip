@@ -1,15 +1,15 @@
 // Edge attributes (EdgeLength, EdgeDirection) and global normalisation for gfx950.
 //
 // The attribute kernel is bound by vector arithmetic (four float32 sin/cos evaluations, one
-// float64 arctangent and the float64 rotation per edge), not by its 20 B/edge of streamed
+// float32 arctangent and the float64 rotation per edge), not by its 20 B/edge of streamed
 // traffic plus the cached endpoint gathers, so the design removes work rather than bytes:
 //  * everything that depends on the target node only (its unit vector, the quaternion that takes
 //    it to the pole and the rotation matrix) is computed once per run of equal targets inside a
 //    block's chunk of edges and staged in LDS.  Edge lists from the builders are grouped by
 //    target, so a run is a target's whole row; an ungrouped list degrades to one run per edge,
 //    never to a wrong result;
-//  * float64 square roots and divisions use reciprocal (square root) seeds refined by two
-//    Newton steps, and the arctangent is a 17-term polynomial after one division.
+//  * float64 square roots use reciprocal square root seeds refined by two Newton steps; the
+//    arctangent of the length is a 9-term float32 polynomial after one float32 division.
 //
 // Precision contract
 //  * The reference evaluates cos/sin of float32 coordinates with numpy's float32 kernels.  numpy's
@@ -19,12 +19,15 @@
 //    FMA-capable x86.  Arguments are latitudes/longitudes (|x| << 71476, the range of that path).
 //  * float32 products, sums and square roots are single IEEE operations (the library is built
 //    with -ffp-contract=off).
-//  * atan2 and the rotation (scipy's Rotation.from_rotvec(...).apply(...): unit quaternion ->
-//    matrix -> product) are evaluated in float64 to within a few float64 ulp (arctangent: 5e-15
-//    relative) and rounded to float32 once, so a stored value differs from the float32 rounding of
-//    the exact result in about one value per 10^7, by one float32 ulp.  The quaternion is formed
-//    with half-angle identities; normalisations of vectors that are unit by construction to
-//    within one float64 ulp are not repeated.
+//  * the rotation (scipy's Rotation.from_rotvec(...).apply(...): unit quaternion -> matrix ->
+//    product) is evaluated in float64 to within a few float64 ulp and rounded to float32 once, so a
+//    stored direction differs from the float32 rounding of the exact result in about one value per
+//    10^7, by one float32 ulp.  The quaternion is formed with half-angle identities;
+//    normalisations of vectors that are unit by construction to within one float64 ulp are not
+//    repeated.
+//  * the length's atan2 is evaluated in float32 to within 1.6 ulp of the exact value (the
+//    reference's numpy float32 arctan2 is within 2 ulp; the two differ by at most 3.1e-7
+//    relative, inside the 1e-6 the parity tests allow).
 #include "ag_common.hpp"
 
 #define AG_ATTR_CHUNK 128  // edges per wave iteration (two per lane)
@@ -50,36 +53,30 @@ __device__ __forceinline__ double ag_rsqrt_f64(double x) {
 // sqrt(x) for x >= 0 (normal or zero)
 __device__ __forceinline__ double ag_sqrt_f64(double x) { return x > 0.0 ? x * ag_rsqrt_f64(x) : 0.0; }
 
-// Coefficients of the arctangent polynomial, highest degree first.  They are passed to the kernel as
-// an argument so that they live in scalar registers: a float64 literal cannot be an instruction
-// operand, and a vector register pair per coefficient would have to be reloaded for every term.
-struct AgAtanCoef {
-  double q[17];
-};
-static const AgAtanCoef AG_ATAN_COEF = {{
-    -0x1.116cf4eed9ee2p-14, 0x1.478bc19252cd1p-11, -0x1.7239c656c970bp-9, 0x1.090411c9f7d90p-7,
-    -0x1.11a34bdf175c0p-6, 0x1.bb63244527d8fp-6, -0x1.2e09b36d6dd7ep-5, 0x1.705f0bf9c30f1p-5,
-    -0x1.a871f31487e16p-5, 0x1.e0520791dacd2p-5, -0x1.10ef041012eacp-4, 0x1.3b0f9b9c5c124p-4,
-    -0x1.745cc3b58ce48p-4, 0x1.c71c6db0fec78p-4, -0x1.24924917024dcp-3, 0x1.9999999975b97p-3,
-    -0x1.55555555554d6p-2}};
-
-// atan2(y, x) for y, x >= 0, not both zero; NaN if either is NaN.  atan(t) = t + t s Q(s), s = t^2,
-// on t = min/max in [0, 1]; Q interpolates (atan(t)/t - 1)/s at 17 Chebyshev nodes (tools/fit_atan.py).
-__device__ __forceinline__ double ag_atan2_pos(double y, double x, const AgAtanCoef& K) {
-  const double hi = fmax(x, y), lo = fmin(x, y);
-  double r = __builtin_amdgcn_rcp(hi);
-  double e = __builtin_fma(-hi, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-hi, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  double t = lo * r;
-  t = __builtin_fma(__builtin_fma(-hi, t, lo), r, t);
-  const double s = t * t;
-  double p = K.q[0];
-#pragma unroll
-  for (int i = 1; i < 17; ++i) p = __builtin_fma(p, s, K.q[i]);
-  const double at = __builtin_fma(t * s, p, t);
-  double res = (y > x) ? (AG_HALF_PI - at) : at;
+// atan2(y, x) for y, x >= 0, not both zero, entirely in float32: atan(t) = t + t s P(s), s = t^2, on t = min/max in
+// [0, 1], P of degree 8 interpolating (atan(t)/t - 1)/s at 9 Chebyshev nodes (tools/fit_atan_f32.py); the quotient
+// is a reciprocal seed with one Newton step and a residual correction.  Over the range of the haversine term the
+// length 2 atan2(sqrt(a), sqrt(1 - a)) is within 1.6 float32 ulp (1.53e-7 relative) of the exact value -- numpy's own
+// float32 arctan2, which the reference calls (utils.py:103), is within 2.5e-7 on x86, and the two differ by at most
+// 3.1e-7 -- at a quarter of the issue slots of the float64 polynomial.  NaN if either argument is NaN.
+__device__ __forceinline__ float ag_atan2_pos_f32(float y, float x) {
+  const float hi = fmaxf(x, y), lo = fminf(x, y);
+  float r = __builtin_amdgcn_rcpf(hi);
+  r = __fmaf_rn(__fmaf_rn(-hi, r, 1.0f), r, r);
+  float t = lo * r;
+  t = __fmaf_rn(__fmaf_rn(-hi, t, lo), r, t);
+  const float s = t * t;
+  float p = -0x1.38de56p-9f;
+  p = __fmaf_rn(p, s, 0x1.ba9f66p-7f);
+  p = __fmaf_rn(p, s, -0x1.25dc12p-5f);
+  p = __fmaf_rn(p, s, 0x1.0001c6p-4f);
+  p = __fmaf_rn(p, s, -0x1.6295f8p-4f);
+  p = __fmaf_rn(p, s, 0x1.c3f168p-4f);
+  p = __fmaf_rn(p, s, -0x1.246cd2p-3f);
+  p = __fmaf_rn(p, s, 0x1.99983cp-3f);
+  p = __fmaf_rn(p, s, -0x1.555554p-2f);
+  const float at = __fmaf_rn(t * s, p, t);
+  float res = (y > x) ? ((0x1.921fb6p+0f - at) + -0x1.777a5cp-25f) : at;  // pi/2 in two float32 pieces
   if (x != x || y != y) res = x + y;
   return res;
 }
@@ -150,7 +147,7 @@ __device__ __forceinline__ void ag_attr_target(float2 tp, bool rotated, AgAttrRu
 // One edge: utils.haversine_distance (utils.py:99-103) in float32 and the direction of the
 // rotated source with respect to the pole (edges/directional.py:68-94).
 __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int r, bool rotated, bool want_len,
-                                             bool want_dir, const AgAtanCoef& K, float* len, double2* dir) {
+                                             bool want_dir, float* len, double2* dir) {
   const float tlat = R.lat[r], tlon = R.lon[r];
   float ss, cs;
   ag_np_sincos_f32(sp.x, &ss, &cs);
@@ -162,7 +159,7 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
     const float s1 = ag_np_sin_f32(dlon / 2.0f);
     const float a = s0 * s0 + cs * ct * (s1 * s1);
     const float y = ag_sqrt_f32_rn(a), x = ag_sqrt_f32_rn(1.0f - a);
-    *len = 2.0f * static_cast<float>(ag_atan2_pos(static_cast<double>(y), static_cast<double>(x), K));
+    *len = 2.0f * ag_atan2_pos_f32(y, x);
   }
   if (want_dir) {
     if (!rotated) {
@@ -203,8 +200,8 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
                                                             const int32_t* __restrict__ es,
                                                             const int32_t* __restrict__ et, int64_t E, int flags,
                                                             float* __restrict__ out_len, float2* __restrict__ out_dir,
-                                                            unsigned* __restrict__ len_range, const AgAtanCoef K,
-                                                            int ns_last, int nt_last, int* __restrict__ bad) {
+                                                            unsigned* __restrict__ len_range, int ns_last, int nt_last,
+                                                            int* __restrict__ bad) {
   __shared__ AgAttrRuns R_all[4];
   const bool rotated = (flags & AG_ATTR_ROTATED) != 0 && out_dir != nullptr;
   const bool want_len = out_len != nullptr, want_dir = out_dir != nullptr;
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256) void ag_edge_attrs_kernel(const float2* __rest
       if (!valid[j]) continue;
       float len;
       double2 dir;
-      ag_attr_edge(g.sp[j], R, run[j], rotated, want_len, want_dir, K, &len, &dir);
+      ag_attr_edge(g.sp[j], R, run[j], rotated, want_len, want_dir, &len, &dir);
       if (want_len) {
         len_c[j * 64 + lane] = len;
         const unsigned b = __float_as_uint(len);
@@ -377,7 +374,7 @@ extern "C" int ag_edge_attrs_range(const float* d_src_x, int64_t ns, const float
   if (!empty) {
     AG_REQUIRE(d_src_x && d_tgt_x && d_edge_src && d_edge_tgt, "ag_edge_attrs: null pointer");
     const int blocks = ag_blocks(E, 4 * AG_ATTR_CHUNK, AG_ATTR_MAX_BLOCKS);
-    AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(blocks), dim3(256), s, reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), want_range ? d_len_range : nullptr, AG_ATAN_COEF, static_cast<int>(ns - 1), static_cast<int>(nt - 1), d_bad);
+    AG_KERNEL("ag_edge_attrs_kernel", ag_edge_attrs_kernel, dim3(blocks), dim3(256), s, reinterpret_cast<const float2*>(d_src_x), reinterpret_cast<const float2*>(d_tgt_x), d_edge_src, d_edge_tgt, E, flags, d_len, reinterpret_cast<float2*>(d_dir), want_range ? d_len_range : nullptr, static_cast<int>(ns - 1), static_cast<int>(nt - 1), d_bad);
     AG_LAUNCH_CHECK();
   }
   if (d_len_range != nullptr) {

@@ -1154,7 +1154,7 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
 // Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends.
 // In host code the array's name is only a handle for hipGetSymbolAddress: the address that kernels, copies and
 // fills may use is the one that call returns for the current device, looked up once per device and kept.
-#define AG_STATIC_SCRATCH_BYTES (size_t(32) << 20)
+#define AG_STATIC_SCRATCH_BYTES (size_t(40) << 20)
 static __device__ __align__(256) unsigned char ag_static_scratch[AG_STATIC_SCRATCH_BYTES];
 
 #define AG_STATIC_MAX_DEVICES 64
@@ -1180,10 +1180,10 @@ extern "C" int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out
   AG_REQUIRE(n <= AG_NN_MAXDIST_STATIC_MAX_N,
              "ag_nn_maxdist_static: %lld points exceed the %d the built-in scratch array holds; use ag_nn_maxdist with a "
              "workspace", static_cast<long long>(n), AG_NN_MAXDIST_STATIC_MAX_N);
-  AG_REQUIRE(d_pts && d_out_max, "ag_nn_maxdist_static: null pointer");
   const size_t need = ag_nn_maxdist_workspace_bytes(n);
   AG_REQUIRE(need <= AG_STATIC_SCRATCH_BYTES, "ag_nn_maxdist_static: %zu bytes of scratch needed, %zu built in", need,
              AG_STATIC_SCRATCH_BYTES);
+  AG_REQUIRE(d_pts && d_out_max, "ag_nn_maxdist_static: null pointer");
   void* scratch = nullptr;
   const int rc = ag_static_scratch_address(&scratch);
   if (rc) return rc;

@@ -61,3 +61,14 @@ def test_id_table_sizes_are_validated_without_gpu():
     assert lib.ag_edge_attrs(None, 0, None, 10, None, None, 4, 1, None, None, None, None) == -1
     assert b"4 edges" in lib.ag_last_error()
     assert lib.ag_edge_attrs(None, 2**31, None, 10, None, None, 4, 1, None, None, None, None) == -1
+
+
+def test_builtin_scratch_holds_the_largest_input_it_promises():
+    """ag_nn_maxdist_static checks the node count, then that its built-in scratch array holds the workspace of that
+    many nodes, then the pointers -- all before any HIP call: the largest promised input must get as far as the
+    pointer check (a layout change that outgrows the array shows up here, not on the GPU)."""
+    lib = _lib.load()
+    text = HEADER[HEADER.index("#define AG_NN_MAXDIST_STATIC_MAX_N"):]
+    max_n = int(text.split()[2])
+    assert lib.ag_nn_maxdist_static(None, max_n, None, None) == -1 and b"null pointer" in lib.ag_last_error()
+    assert lib.ag_nn_maxdist_static(None, max_n + 1, None, None) == -1 and b"exceed" in lib.ag_last_error()
