@@ -245,11 +245,15 @@ __global__ __launch_bounds__(1024) void ag_ico_small_levels_kernel(int levels, d
                                                                    int32_t* faces_b, uint64_t* level_edges,
                                                                    uint64_t* uniq_scratch, int* g_first,
                                                                    unsigned long long* scan_state, int scan_words,
-                                                                   int* error_flag) {
+                                                                   int* error_flag, int* zero_ptr, int zero_n) {
   __shared__ int s_first[AG_ICO_SMALL_V + 2];
   __shared__ int32_t s_nb[AG_MAX_DEG * AG_ICO_SMALL_V];
   __shared__ int s_scan[32 + 1024];
   const int tid = threadIdx.x;
+  // counters that kernels further down the stream expect to be zero (the error flag of this build, the bucket
+  // counters of the node-order sort)
+  if (tid == 0) *error_flag = 0;
+  for (int i = tid; i < zero_n; i += 1024) zero_ptr[i] = 0;
   {  // icosahedron (trimesh.creation.icosahedron)
     if (tid < 12) {
       const double t = (1.0 + sqrt(5.0)) / 2.0;
@@ -338,8 +342,35 @@ __device__ __forceinline__ uint32_t ag_desc_key(float v) {
 
 // sort input: position p holds node id = n - 1 - p with its key; for the icosphere the coordinates
 // themselves are produced here too (generate/transforms.py:50-52)
+//
+// Node sets of up to AG_ORDER_SMALL_N nodes are not handed to a library sort (a merge sort of nine launches at
+// these sizes): the nodes are dealt into latitude buckets of equal height -- a counting sort, one returning
+// atomic per node -- and the nodes of every bucket are ranked among each other, 64 per wave.  Three
+// launches; the bucket is a monotone function of the latitude, so the buckets are in order among themselves,
+// and ties of a whole key go to the higher id, which makes the result the stable sort's.
+#define AG_ORDER_SMALL_N (1 << 19)
+#define AG_ORDER_MAX_BUCKETS 8192
+#define AG_ORDER_WAVE_CAP 512  // nodes of a bucket a wave ranks from LDS (longer buckets: from global memory)
+#define AG_ORDER_CHUNKS 8    // waves per bucket, 64 nodes each (the waves of a longer bucket take several)
+
+static int ag_order_buckets(int64_t n) {
+  int64_t b = n / 32;
+  if (b < 64) b = 64;
+  if (b > AG_ORDER_MAX_BUCKETS) b = AG_ORDER_MAX_BUCKETS;
+  return static_cast<int>(b);
+}
+
+__device__ __forceinline__ int ag_order_bucket_of(float lat, int B) {
+  // (NaN and latitudes beyond the poles land in the outermost buckets; the key order inside a bucket is exact)
+  const float t = (static_cast<float>(AG_HALF_PI) - lat) * (static_cast<float>(B) * static_cast<float>(1.0 / AG_PI));
+  int b = t > 0.0f ? static_cast<int>(t) : 0;
+  return b < B ? b : B - 1;
+}
+
 __global__ void ag_order_keys_kernel(const double* __restrict__ xyz, float2* __restrict__ latlon, int64_t n,
-                                     uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
+                                     uint64_t* __restrict__ keys, int32_t* __restrict__ ids, int B,
+                                     int* __restrict__ bucket_count, int* __restrict__ bucket_of,
+                                     int* __restrict__ slot_of) {
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     float2 p;
     if (xyz != nullptr) {
@@ -351,9 +382,18 @@ __global__ void ag_order_keys_kernel(const double* __restrict__ xyz, float2* __r
     } else {
       p = latlon[i];
     }
-    const int64_t pos = n - 1 - i;
-    keys[pos] = (static_cast<uint64_t>(ag_desc_key(p.x)) << 32) | ag_desc_key(p.y);
-    ids[pos] = static_cast<int32_t>(i);
+    const uint64_t key = (static_cast<uint64_t>(ag_desc_key(p.x)) << 32) | ag_desc_key(p.y);
+    if (bucket_count != nullptr) {  // bucket path: keys stay in id order, every node takes a slot of its bucket
+      keys[i] = key;
+      // the bucket must not separate equal keys: it is taken from the latitude the key encodes (-0 as +0)
+      const int b = ag_order_bucket_of(p.x + 0.0f, B);
+      bucket_of[i] = b;
+      slot_of[i] = atomicAdd(&bucket_count[b], 1);
+    } else {
+      const int64_t pos = n - 1 - i;
+      keys[pos] = key;
+      ids[pos] = static_cast<int32_t>(i);
+    }
   }
 }
 
@@ -364,6 +404,112 @@ __global__ void ag_order_finish_kernel(const int32_t* __restrict__ order, const 
     const int32_t id = order[i];
     rank[id] = static_cast<int32_t>(i);
     out_latlon[i] = latlon[id];
+  }
+}
+
+// bucket path, second launch: every block turns the bucket counts into bucket starts in LDS (the table is small),
+// then deals its share of the nodes into their buckets; block 0 leaves the starts in global memory for the third.
+__global__ __launch_bounds__(256) void ag_order_scatter_kernel(int64_t n, int B, const int* __restrict__ bucket_count,
+                                                               const int* __restrict__ bucket_of,
+                                                               const int* __restrict__ slot_of,
+                                                               const uint64_t* __restrict__ keys,
+                                                               uint64_t* __restrict__ out_keys,
+                                                               int32_t* __restrict__ out_ids,
+                                                               int* __restrict__ bucket_start) {
+  __shared__ int start[AG_ORDER_MAX_BUCKETS + 1];
+  __shared__ int partial[256];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < B; b += 256) start[b] = bucket_count[b];  // (coalesced; the serial part below reads LDS)
+  __syncthreads();
+  const int per = (B + 255) / 256;
+  const int b0 = tid * per, b1 = min(B, b0 + per);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += start[b];
+  partial[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = (tid >= d) ? partial[tid - d] : 0;
+    __syncthreads();
+    partial[tid] += v;
+    __syncthreads();
+  }
+  int run = partial[tid] - sum;
+  for (int b = b0; b < b1; ++b) {
+    const int count = start[b];
+    start[b] = run;
+    run += count;
+  }
+  if (tid == 255) start[B] = partial[255];
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int b = tid; b <= B; b += 256) bucket_start[b] = start[b];
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + tid; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int pos = start[bucket_of[i]] + slot_of[i];
+    out_keys[pos] = keys[i];
+    out_ids[pos] = static_cast<int32_t>(i);
+  }
+}
+
+// bucket path, third launch: the nodes of every bucket are ranked among each other -- position = number of nodes
+// of the bucket that come first: smaller key, or equal key and higher id -- and the order, the inverse permutation
+// and the ordered coordinates are written.  A wave takes 64 nodes of a bucket (AG_ORDER_CHUNKS waves per bucket;
+// those beyond the bucket's length leave at once) and stages the whole bucket in its slice of LDS (longer buckets
+// are read from global memory); the counting loop is unrolled so that eight LDS reads are in flight.
+__global__ __launch_bounds__(256) void ag_order_bucket_kernel(int B, const int* __restrict__ bucket_start,
+                                                              const uint64_t* __restrict__ keys,
+                                                              const int32_t* __restrict__ ids,
+                                                              const float2* __restrict__ latlon,
+                                                              int32_t* __restrict__ order, float2* __restrict__ out_latlon,
+                                                              int32_t* __restrict__ rank) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_keys_all[4][AG_ORDER_WAVE_CAP];
+  __shared__ __attribute__((aligned(16))) int32_t s_ids_all[4][AG_ORDER_WAVE_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  const int b = item / AG_ORDER_CHUNKS, chunk = item % AG_ORDER_CHUNKS;
+  if (b >= B) return;
+  const int first = bucket_start[b], m = bucket_start[b + 1] - first;  // (wave-uniform)
+  if (chunk * 64 >= m) return;
+  uint64_t* s_keys = s_keys_all[wave];
+  int32_t* s_ids = s_ids_all[wave];
+  const bool staged = m <= AG_ORDER_WAVE_CAP;
+  const int m4 = (m + 3) & ~3;
+  if (staged) {
+    for (int j = lane; j < m4; j += 64) {
+      // (padding to a multiple of four: the largest key with the smallest id comes before no node)
+      s_keys[j] = j < m ? keys[first + j] : ~0ull;
+      s_ids[j] = j < m ? ids[first + j] : static_cast<int32_t>(0x80000000u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  for (int e = chunk * 64 + lane; e < m; e += 64 * AG_ORDER_CHUNKS) {
+    const uint64_t ke = staged ? s_keys[e] : keys[first + e];
+    const int32_t ie = staged ? s_ids[e] : ids[first + e];
+    // no short-circuit: a branch per comparison would expose the latency of every LDS read
+    auto before = [&](uint64_t kj, int32_t ij) {
+      return static_cast<int>(kj < ke) | (static_cast<int>(kj == ke) & static_cast<int>(ij > ie));
+    };
+    int r = 0;
+    if (staged) {
+      const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(s_keys);
+      const int4* i4 = reinterpret_cast<const int4*>(s_ids);
+#pragma unroll 2
+      for (int j = 0; j < m4 / 4; ++j) {
+        const ulonglong2 ka = k2[2 * j], kb = k2[2 * j + 1];
+        const int4 iv = i4[j];
+        r += before(ka.x, iv.x) + before(ka.y, iv.y) + before(kb.x, iv.z) + before(kb.y, iv.w);
+      }
+    } else {
+#pragma unroll 4
+      for (int j = 0; j < m; ++j) r += before(keys[first + j], ids[first + j]);
+    }
+    const int pos = first + r;
+    order[pos] = ie;
+    if (rank != nullptr) {
+      rank[ie] = pos;
+      out_latlon[pos] = latlon[ie];
+    }
   }
 }
 
@@ -380,6 +526,11 @@ struct AgTopoWs {
   uint64_t* keys_a;    // [V_R]     node-order sort keys
   uint64_t* keys_b;    // [V_R]
   int32_t* ids_a;      // [V_R]     node-order sort values
+  int32_t* ids_b;      // [V_R]     bucket path of the node order: ids by bucket, bucket and slot of every node,
+  int* bucket_of;      // [V_R]     bucket counters and starts
+  int* slot_of;        // [V_R]
+  int* bucket_count;   // [AG_ORDER_MAX_BUCKETS + 1]
+  int* bucket_start;   // [AG_ORDER_MAX_BUCKETS + 1]
   void* sort_temp;
   size_t sort_temp_bytes;
   int32_t* faces_a;    // [3 F_R]
@@ -398,6 +549,11 @@ static void ag_topo_carve(AgCarver& c, int R, AgTopoWs* w) {
   t.keys_a = c.take<uint64_t>(V);
   t.keys_b = c.take<uint64_t>(V);
   t.ids_a = c.take<int32_t>(V);
+  t.ids_b = c.take<int32_t>(V);
+  t.bucket_of = c.take<int>(V);
+  t.slot_of = c.take<int>(V);
+  t.bucket_count = c.take<int>(AG_ORDER_MAX_BUCKETS + 1);
+  t.bucket_start = c.take<int>(AG_ORDER_MAX_BUCKETS + 1);
   t.sort_temp_bytes = ag_sort_pairs_u64_i32_temp_bytes(V);
   t.sort_temp = c.take<char>(t.sort_temp_bytes);
   t.faces_a = c.take<int32_t>(3 * F);
@@ -427,15 +583,35 @@ static int ag_topo_unique_edges(const AgTopoWs& w, int* first, const int32_t* fa
 // inverse permutation
 struct AgOrderWs {
   uint64_t *keys_a, *keys_b;
-  int32_t* ids_a;
+  int32_t *ids_a, *ids_b;
+  int *bucket_of, *slot_of, *bucket_count, *bucket_start;
   void* sort_temp;
   size_t sort_temp_bytes;
 };
 
+// `counters_clear`: the caller has a kernel upstream that zeroed w.bucket_count[0 .. AG_ORDER_MAX_BUCKETS]
 static int ag_order_nodes(const double* xyz, float2* latlon, int64_t n, const AgOrderWs& w, int32_t* d_order,
-                          float2* out_latlon, int32_t* rank, hipStream_t s) {
+                          float2* out_latlon, int32_t* rank, bool counters_clear, hipStream_t s) {
   const int nb = ag_blocks(n, 256, 8192);
-  AG_KERNEL("ag_order_keys_kernel", ag_order_keys_kernel, dim3(nb), dim3(256), s, xyz, latlon, n, w.keys_a, w.ids_a);
+  if (n <= AG_ORDER_SMALL_N) {
+    const int B = ag_order_buckets(n);
+    if (!counters_clear) {
+      int rc = ag_zero_i32(w.bucket_count, B + 1, s);
+      if (rc) return rc;
+    }
+    AG_KERNEL("ag_order_keys_kernel", ag_order_keys_kernel, dim3(nb), dim3(256), s, xyz, latlon, n, w.keys_a, w.ids_a, B,
+              w.bucket_count, w.bucket_of, w.slot_of);
+    AG_LAUNCH_CHECK();
+    AG_KERNEL("ag_order_scatter_kernel", ag_order_scatter_kernel, dim3(ag_blocks(n, 1024, 1024)), dim3(256), s, n, B,
+              w.bucket_count, w.bucket_of, w.slot_of, w.keys_a, w.keys_b, w.ids_b, w.bucket_start);
+    AG_LAUNCH_CHECK();
+    AG_KERNEL("ag_order_bucket_kernel", ag_order_bucket_kernel, dim3((B * AG_ORDER_CHUNKS + 3) / 4), dim3(256), s, B,
+              w.bucket_start, w.keys_b, w.ids_b, latlon, d_order, out_latlon, rank);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+  }
+  AG_KERNEL("ag_order_keys_kernel", ag_order_keys_kernel, dim3(nb), dim3(256), s, xyz, latlon, n, w.keys_a, w.ids_a, 0,
+            static_cast<int*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr));
   AG_LAUNCH_CHECK();
   int rc = ag_sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.ids_a, d_order, n, s);
   if (rc) return rc;
@@ -452,6 +628,11 @@ static void ag_node_order_carve(AgCarver& c, int64_t n, AgOrderWs* w) {
   t.keys_a = c.take<uint64_t>(n);
   t.keys_b = c.take<uint64_t>(n);
   t.ids_a = c.take<int32_t>(n);
+  t.ids_b = c.take<int32_t>(n);
+  t.bucket_of = c.take<int>(n);
+  t.slot_of = c.take<int>(n);
+  t.bucket_count = c.take<int>(AG_ORDER_MAX_BUCKETS + 1);
+  t.bucket_start = c.take<int>(AG_ORDER_MAX_BUCKETS + 1);
   t.sort_temp_bytes = ag_sort_pairs_u64_i32_temp_bytes(n);
   t.sort_temp = c.take<char>(t.sort_temp_bytes);
   if (w) *w = t;
@@ -474,7 +655,7 @@ extern "C" int ag_node_order(const float* d_latlon, int64_t n, int32_t* d_order,
   AgOrderWs w;
   ag_node_order_carve(c, n, &w);
   return ag_order_nodes(nullptr, const_cast<float2*>(reinterpret_cast<const float2*>(d_latlon)), n, w, d_order, nullptr,
-                        nullptr, static_cast<hipStream_t>(stream));
+                        nullptr, false, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ag_icosphere_sizes(int R, int64_t* V, int64_t* F, int64_t* E_all) {
@@ -506,12 +687,13 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   // ping-pong between the caller's face buffer and the workspace so that level R lands in d_faces
   int32_t* cur = (R % 2 == 0) ? d_faces : w.faces_a;
   int32_t* nxt = (R % 2 == 0) ? w.faces_a : d_faces;
-  int rc = ag_zero_i32(w.error_flag, 1, s);
-  if (rc) return rc;
-  // levels 0 .. small-1 in one block; the face ping-pong continues from where it ends
+  int rc = AG_OK;
+  // levels 0 .. small-1 in one block; the face ping-pong continues from where it ends.  The same kernel clears the
+  // error flag and the bucket counters of the node-order sort at the end of this call.
   const int small = R < AG_ICO_SMALL_LEVELS ? R : AG_ICO_SMALL_LEVELS;
   AG_KERNEL("ag_ico_small_levels_kernel", ag_ico_small_levels_kernel, dim3(1), dim3(1024), s, small, d_xyz, cur, nxt,
-            d_level_edges, w.uniq, w.first, w.scan_state, static_cast<int>(w.scan_words), w.error_flag);
+            d_level_edges, w.uniq, w.first, w.scan_state, static_cast<int>(w.scan_words), w.error_flag, w.bucket_count,
+            AG_ORDER_MAX_BUCKETS + 1);
   AG_LAUNCH_CHECK();
   if (small % 2 == 1) {
     int32_t* t = cur;
@@ -556,9 +738,14 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   ow.keys_a = w.keys_a;
   ow.keys_b = w.keys_b;
   ow.ids_a = w.ids_a;
+  ow.ids_b = w.ids_b;
+  ow.bucket_of = w.bucket_of;
+  ow.slot_of = w.slot_of;
+  ow.bucket_count = w.bucket_count;
+  ow.bucket_start = w.bucket_start;
   ow.sort_temp = w.sort_temp;
   ow.sort_temp_bytes = w.sort_temp_bytes;
-  return ag_order_nodes(d_xyz, latlon, V, ow, d_order, reinterpret_cast<float2*>(d_latlon), d_rank, s);
+  return ag_order_nodes(d_xyz, latlon, V, ow, d_order, reinterpret_cast<float2*>(d_latlon), d_rank, true, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -152,3 +152,42 @@ def test_knn_within_a_distance_bound(device, k, bound_km, n_ref, seed):
         rows = np.where(keep & (ids != want_i))
         np.testing.assert_allclose(dist[rows], want_d[rows], rtol=1e-12)
     assert np.all(np.isinf(dist[~inside & ~edge])) and np.all(ids[~inside & ~edge] == -1)
+
+
+@pytest.mark.parametrize("case", ["one", "two_equal", "random_70k", "rows", "one_latitude", "all_equal", "poles_and_zero",
+                                  "threshold", "above_threshold"])
+def test_node_order_cases(device, case):
+    """ag_node_order against the stable-sort order of generate/utils.py:30-32 on node sets that stress the bucket
+    path (latitude buckets + one wave per bucket): whole rows of equal latitude, a single latitude (one bucket longer
+    than a wave's LDS share), coincident nodes (ties go to the higher id), both poles, signed zeros; and on both
+    sides of the size at which the library sort takes over."""
+    rng = np.random.default_rng(7)
+    if case == "one":
+        x = np.array([[0.3, 1.0]], dtype=np.float32)
+    elif case == "two_equal":
+        x = np.array([[0.3, 1.0], [0.3, 1.0]], dtype=np.float32)
+    elif case == "random_70k":
+        x = grids.random_sphere(70_000, seed=5)
+    elif case == "rows":  # a regular grid: rows of 360 nodes of exactly equal latitude
+        x = grids.regular(1.0)
+    elif case == "one_latitude":  # 5,000 nodes in one bucket
+        x = np.stack([np.full(5000, 0.25), rng.uniform(0, 2 * np.pi, 5000)], axis=1).astype(np.float32)
+    elif case == "all_equal":
+        x = np.tile(np.array([[0.5, 2.0]], dtype=np.float32), (3000, 1))
+    elif case == "poles_and_zero":
+        x = np.array([[np.pi / 2, 0.0], [-np.pi / 2, 3.0], [0.0, 1.0], [-0.0, 1.0], [0.0, -0.0], [np.pi / 2, 1.0],
+                      [1e-30, 0.5], [-1e-30, 0.5]] * 40, dtype=np.float32)
+    elif case == "threshold":
+        x = grids.random_sphere(1 << 19, seed=6)
+    else:
+        x = grids.random_sphere((1 << 19) + 1, seed=6)
+    got = ops.node_order(torch.as_tensor(x)).cpu().numpy()
+    want = rp.coordinates_ordering_canonical(x.astype(np.float64))
+    if case == "poles_and_zero":
+        # numpy orders -0.0 and +0.0 as equal too; compare the ordered coordinates and the tie rule
+        assert np.array_equal(x[got] + 0.0, x[want] + 0.0)
+        lat, lon = x[got, 0] + 0.0, x[got, 1] + 0.0
+        tie = (lat[1:] == lat[:-1]) & (lon[1:] == lon[:-1])
+        assert np.all(got[1:][tie] < got[:-1][tie])  # equal coordinates: descending id
+    else:
+        assert np.array_equal(got, want)
