@@ -284,11 +284,13 @@ struct AgKnnArgs {
   int range_len;             // 64 for dense target sets; fewer for a set queried against itself (sparse: the window grows with the span)
   const int* tcell_of;       // cell of every target, by original id
   int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
+  int ranges_in_lds;         // 1: the window kernel works that table out itself (few bands), range_off is not used
   int bounded;               // 1: neighbours farther than rmax are not wanted (their entries become -1)
   double rmax_window;        // bounded: the widest window stage 2 scans (rmax and a rounding pad)
   double rmax_rdist;         // bounded: sin^2(rmax / 2), the acceptance threshold on the reduced distance
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
   unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
+  double* out_max;           // reference-distance mode: where the largest nearest-neighbour distance goes
   long long* stats;          // [4]
 };
 
@@ -403,15 +405,52 @@ __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
 
 // one thread per descriptor: the targets of the wave and the runs of sources that cover them (stage 1
 // then starts with one load instead of a chain of dependent table look-ups per wave)
-__global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
+#define AG_KNN_LDS_BANDS 4096  // band tables up to this size are rebuilt in LDS by every block of the window kernel
+__global__ __launch_bounds__(256) void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the stages that follow
     a.queue_count[0] = 0;  // stage-2 queue
     a.queue_count[1] = 0;  // float64 re-rank queue
+    a.queue_count[2] = 0;  // blocks of stage 2 that have finished
     if (a.max_bits) *a.max_bits = 0ull;
     if (a.stats) a.stats[0] = a.stats[1] = a.stats[2] = a.stats[3] = 0;
   }
   const int nb = a.tgrid.nb;
-  const int used = a.by_range ? a.range_off[nb] : a.tgrid.off[nb];
+  // Descriptors by ranges: the first descriptor of every band.  With few enough bands every block works the table
+  // out for itself in LDS (a prefix sum over the band populations), which saves the one-block kernel that would
+  // otherwise precede this one and turns the binary searches below into LDS reads.
+  __shared__ int s_range_off[AG_KNN_LDS_BANDS + 1];
+  __shared__ int s_partial[256];
+  const int* range_off = a.range_off;
+  if (a.by_range && a.ranges_in_lds) {
+    const int tid = threadIdx.x;
+    for (int b = tid; b < nb; b += 256) {
+      const int cnt = a.tstart[a.tgrid.off[b + 1]] - a.tstart[a.tgrid.off[b]];
+      s_range_off[b] = (cnt + a.range_len - 1) / a.range_len;
+    }
+    __syncthreads();
+    const int per = (nb + 255) / 256;
+    const int b_begin = tid * per, b_end = min(nb, b_begin + per);
+    int sum = 0;
+    for (int b = b_begin; b < b_end; ++b) sum += s_range_off[b];
+    s_partial[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int v = (tid >= d) ? s_partial[tid - d] : 0;
+      __syncthreads();
+      s_partial[tid] += v;
+      __syncthreads();
+    }
+    int run = s_partial[tid] - sum;
+    for (int b = b_begin; b < b_end; ++b) {
+      const int cnt = s_range_off[b];
+      s_range_off[b] = run;
+      run += cnt;
+    }
+    if (tid == 255) s_range_off[nb] = s_partial[255];
+    __syncthreads();
+    range_off = s_range_off;
+  }
+  const int used = a.by_range ? range_off[nb] : a.tgrid.off[nb];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.nwin; i += gridDim.x * blockDim.x) {
     AgWindow w;
     w.t0 = w.t1 = 0;
@@ -425,11 +464,11 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
         int lo = 0, hi = nb - 1;  // last band whose first range is <= i (bands without targets share an offset)
         while (lo < hi) {
           const int mid = (lo + hi + 1) >> 1;
-          if (a.range_off[mid] <= i) lo = mid; else hi = mid - 1;
+          if (range_off[mid] <= i) lo = mid; else hi = mid - 1;
         }
         band = lo;
         const int b0 = a.tstart[a.tgrid.off[band]], b1 = a.tstart[a.tgrid.off[band + 1]];
-        w.t0 = b0 + a.range_len * (i - a.range_off[band]);
+        w.t0 = b0 + a.range_len * (i - range_off[band]);
         w.t1 = min(w.t0 + a.range_len, b1);
         // binned targets are ordered by cell, so the cells of the first and the last target bound the rest
         col_first = a.tcell_of[a.tids[w.t0]] - a.tgrid.off[band];
@@ -865,11 +904,19 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       if (rounds) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), static_cast<unsigned long long>(rounds));
     }
   }
-}
-
-__global__ void ag_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
-  const double r = __longlong_as_double(static_cast<long long>(*max_bits));
-  *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
+  if (a.out_max != nullptr) {
+    // reference-distance mode: the block that finishes last (every block counts itself in after its own updates of
+    // the running maximum are visible) turns the largest reduced distance into the distance
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const int done = atomicAdd(a.queue_count + 2, 1);
+      if (done == static_cast<int>(gridDim.x) - 1) {
+        const double r = __longlong_as_double(static_cast<long long>(atomicMax(a.max_bits, 0ull)));
+        *a.out_max = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
+      }
+    }
+  }
 }
 
 // cell size for a k-NN search over ns quasi-uniform sources: the disc of radius delta holds
@@ -1042,9 +1089,11 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     a.rmax_rdist = sh * sh;
   }
   a.max_bits = w.max_bits;
+  a.out_max = self_query ? d_out_max : nullptr;
   a.stats = reinterpret_cast<long long*>(d_stats);
 
-  if (a.by_range) {
+  a.ranges_in_lds = (a.by_range && w.tgt.grid.nb <= AG_KNN_LDS_BANDS) ? 1 : 0;
+  if (a.by_range && !a.ranges_in_lds) {
     AG_KERNEL("ag_knn_band_ranges_kernel", ag_knn_band_ranges_kernel, dim3(1), dim3(1024), stream, a);
     AG_LAUNCH_CHECK();
   }
@@ -1061,12 +1110,11 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     default: ag_launch_stage1<AG_KNN_MAX_K + 2>(a, stream); break;
   }
   AG_LAUNCH_CHECK();
-  AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
+  // (the queue is short as a rule -- the waves stride over it -- so a modest grid; in reference-distance mode its
+  // last block also writes the result)
+  AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(512), dim3(256), stream, a);
   AG_LAUNCH_CHECK();
-  if (self_query) {
-    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1), stream, w.max_bits, d_out_max);
-    AG_LAUNCH_CHECK();
-  } else if (d_out_dist != nullptr || a.bounded) {
+  if (!self_query && (d_out_dist != nullptr || a.bounded)) {
     AG_KERNEL("ag_knn_dist_kernel", ag_knn_dist_kernel, dim3(ag_blocks(nt * k, 256, 16384)), dim3(256), stream, a);
     AG_LAUNCH_CHECK();
   }
