@@ -73,6 +73,8 @@ SIGNATURES = {
     "ag_node_order": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
     "ag_mark_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     "ag_invert_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
+    "ag_scan_i32_state_words": (c_size_t, [c_int64]),
+    "ag_scan_i32": (c_int, [_P, _P, c_int64, _P, c_int, _P]),
     "ag_fill_row_ids": (c_int, [_P, c_int64, c_int, _P]),
 }
 

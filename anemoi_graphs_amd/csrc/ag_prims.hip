@@ -228,7 +228,13 @@ int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream) {
 // out[n] receives the total (and *total_out, if given); with want_max, out[n + 1] the largest input
 // value.  in == out is allowed.
 // ---------------------------------------------------------------------------------------------
-#define AG_SCAN_HEADER 8  // [0] ticket, [1] tiles finished, [2] running maximum
+#define AG_SCAN_HEADER 8  // [0] ticket, [1] tiles finished, [2] running maximum, [3] error word
+// A tile that has polled a predecessor this often without seeing it publish gives up: it sets the error word,
+// counts the missing predecessors as zero and goes on, so that every block of the launch ends whatever the state
+// words held (stale words of a workspace nobody cleared would otherwise be waited for for ever).  The tile that
+// writes the total writes -1 instead when the error word is set.  (A poll takes about 0.1 us: the limit is some
+// tenths of a second, far beyond any wait for a tile that is actually running.)
+#define AG_SCAN_SPIN_LIMIT (1 << 22)
 
 template <class T>
 struct AgScanTile;
@@ -264,7 +270,7 @@ __device__ __forceinline__ void ag_scan_state_store(unsigned long long* p, unsig
 template <class T>
 __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* out, int64_t n,
                                                               unsigned long long* __restrict__ state, int want_max,
-                                                              long long* __restrict__ total_out) {
+                                                              long long* __restrict__ total_out, int spin_limit) {
   constexpr int ITEMS = AgScanTile<T>::ITEMS;
   constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_PREFIX = 2ull << 62, VALUE = (1ull << 62) - 1ull;
   __shared__ unsigned s_tile;
@@ -276,6 +282,10 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
   __syncthreads();
   const int64_t tile = s_tile;
   const int64_t ntiles = (n + 256 * ITEMS - 1) / (256 * ITEMS);
+  if (tile >= ntiles) {  // a ticket beyond the tiles of this scan: the state words were not zero at launch
+    if (tid == 0) ag_scan_state_store(state + 3, 1ull);
+    return;
+  }
   const int64_t first = tile * (256 * ITEMS) + int64_t(tid) * ITEMS;
   long long v[ITEMS];
   long long sum = 0, mx = 0;
@@ -323,6 +333,10 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
           __builtin_amdgcn_s_sleep(1);
           ++polls;
           if (idx >= 0 && (st >> 62) == 0ull) st = ag_scan_state_load(state + AG_SCAN_HEADER + idx, polls);
+          if (polls >= spin_limit) {  // (wave-uniform) give up: see AG_SCAN_SPIN_LIMIT
+            if ((st >> 62) == 0ull) st = FLAG_PREFIX;  // the missing predecessors count as zero; the look-back ends here
+            if (lane == 0) ag_scan_state_store(state + 3, 1ull);
+          }
         }
         const unsigned long long has_prefix = __ballot((st >> 62) == 2ull);
         const int stop = has_prefix ? (__ffsll(static_cast<long long>(has_prefix)) - 1) : 64;
@@ -347,8 +361,11 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
     run += v[i];
   }
   if (tile == ntiles - 1 && tid == 255) {
-    out[n] = static_cast<T>(s_prefix + block_total);
-    if (total_out != nullptr) *total_out = s_prefix + block_total;
+    // (every predecessor has published before this tile got here, so an error any of them met is visible)
+    const bool failed = __hip_atomic_load(state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    const long long total = failed ? -1ll : s_prefix + block_total;
+    out[n] = static_cast<T>(total);
+    if (total_out != nullptr) *total_out = total;
   }
   if (want_max && tid == 0) {
     long long m = s_max[0];
@@ -365,7 +382,7 @@ int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long lo
                         long long* d_total) {
   if (n <= 0) return AG_OK;
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int>, dim3(static_cast<unsigned>(ag_scan_tiles<int>(n))),
-            dim3(256), stream, d_in, d_out, n, d_state, 0, d_total);
+            dim3(256), stream, d_in, d_out, n, d_state, 0, d_total, AG_SCAN_SPIN_LIMIT);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -375,7 +392,23 @@ int ag_chained_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n, unsigned
   if (n <= 0) return AG_OK;
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int64_t>,
             dim3(static_cast<unsigned>(ag_scan_tiles<int64_t>(n))), dim3(256), stream, d_in, d_out, n, d_state, want_max,
-            static_cast<long long*>(nullptr));
+            static_cast<long long*>(nullptr), AG_SCAN_SPIN_LIMIT);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+// The single-launch scan on its own, with the bound of its look-back wait as an argument (tests force the
+// give-up path with stale state words and a tiny bound; every block still ends).  d_state: *d_state_words 64-bit
+// words, all zero for a valid scan; d_out: n + 1 entries, d_out[n] = total, or -1 if a tile gave up.
+extern "C" size_t ag_scan_i32_state_words(int64_t n) { return ag_chained_scan_state_words_i32(n); }
+extern "C" int ag_scan_i32(const int32_t* d_in, int32_t* d_out, int64_t n, unsigned long long* d_state, int spin_limit,
+                           void* stream) {
+  AG_REQUIRE(n >= 1 && n < (int64_t(1) << 31), "ag_scan_i32: size out of range");
+  AG_REQUIRE(spin_limit >= 1, "ag_scan_i32: the spin limit must be positive");
+  AG_REQUIRE(d_in && d_out && d_state, "ag_scan_i32: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int>, dim3(static_cast<unsigned>(ag_scan_tiles<int>(n))),
+            dim3(256), s, d_in, d_out, n, d_state, 0, static_cast<long long*>(nullptr), spin_limit);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

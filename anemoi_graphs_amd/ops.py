@@ -263,6 +263,9 @@ def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, src_binnin
                 "ag_radius_count_binned",
             )
         num_edges, max_row = offsets[nt:].tolist()  # the one host synchronisation: output size, longest row
+        if num_edges < 0:
+            raise _lib.LibraryError("ag_radius_count: the scan of the row lengths gave up waiting for a tile "
+                                    "(workspace state not cleared?)")
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
         if num_edges and src_binning is None:
             _lib.check(

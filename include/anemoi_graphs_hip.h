@@ -317,6 +317,15 @@ int ag_remap_ids(int32_t* d_values, int64_t n, const int32_t* d_map, int64_t n_m
 int ag_mark_ids(const int32_t* d_ids, int64_t n, uint8_t* d_mask, int64_t n_mask, int32_t* d_bad, void* stream);
 int ag_invert_ids(const int32_t* d_ids, int64_t n, int32_t* d_map, int64_t n_map, int32_t* d_bad, void* stream);
 
+/* Exclusive prefix sum of n int32 values in ONE launch (chained tiles with look-back), the primitive behind the
+ * cell starts of every binning and the row offsets of the cut-off query; no counterpart in the reference.
+ * d_out holds n + 1 entries (d_out[n] = total).  d_state: ag_scan_i32_state_words(n) 64-bit words that MUST be zero
+ * when the call is made (inside the library a kernel that runs upstream anyway clears them).  A tile waits for its
+ * predecessors at most spin_limit polls: if the words were stale the wait gives up, every block still ends, and
+ * d_out[n] is -1 instead of the total. */
+size_t ag_scan_i32_state_words(int64_t n);
+int ag_scan_i32(const int32_t* d_in, int32_t* d_out, int64_t n, unsigned long long* d_state, int spin_limit, void* stream);
+
 /* Target column of a fixed-degree edge list: d_out[r * k + j] = r for r < rows, j < k.
  * Replaces the COO row array the reference takes from kneighbors_graph(...).tocoo()
  * (edges/builder.py:80-84: edge_index row 1 = adjacency row = target id). */

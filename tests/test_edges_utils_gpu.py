@@ -84,3 +84,31 @@ def test_post_processor_rejects_edges_to_missing_nodes(device):
     graph[("a", "to", "a")].edge_index = torch.tensor([[0, 1, 12], [1, 2, 3]], dtype=torch.int32)
     with pytest.raises(IndexError):
         RemoveUnconnectedNodes("a").update_graph(graph)
+
+
+def test_single_launch_scan_and_its_bounded_wait(device):
+    """The chained-tile scan (cell starts, row offsets): correct on zeroed state words; on STALE state words -- the
+    ticket counter not at zero, so that a tile waits for a predecessor that never runs -- its look-back gives up
+    after the bound the host passes, every block ends, and the total reads -1.  (The wait is bounded by the kernel
+    itself: nothing here hangs or faults the GPU.)"""
+    import ctypes
+
+    from anemoi_graphs_amd import _lib
+
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    for n in (1, 4096, 4097, 1_000_003):
+        values = torch.randint(0, 7, (n,), dtype=torch.int32, device=device)
+        out = torch.empty(n + 1, dtype=torch.int32, device=device)
+        state = torch.zeros(lib.ag_scan_i32_state_words(n), dtype=torch.int64, device=device)
+        _lib.check(lib.ag_scan_i32(values.data_ptr(), out.data_ptr(), n, state.data_ptr(), 1 << 22, stream), "ag_scan_i32")
+        want = torch.cumsum(values.long(), 0)
+        assert int(out[n]) == int(want[-1]) and torch.equal(out[1:n].long(), want[:-1]) and int(out[0]) == 0
+    n = 40_000  # ten tiles
+    values = torch.ones(n, dtype=torch.int32, device=device)
+    out = torch.zeros(n + 1, dtype=torch.int32, device=device)
+    state = torch.zeros(lib.ag_scan_i32_state_words(n), dtype=torch.int64, device=device)
+    state[0] = 1  # stale ticket counter: tile 0 never runs, tile 1 waits for it in vain
+    _lib.check(lib.ag_scan_i32(values.data_ptr(), out.data_ptr(), n, state.data_ptr(), 16, stream), "ag_scan_i32")
+    torch.cuda.synchronize(device)
+    assert int(state[3]) == 1  # the error word
