@@ -284,13 +284,11 @@ struct AgKnnArgs {
   int range_len;             // 64 for dense target sets; fewer for a set queried against itself (sparse: the window grows with the span)
   const int* tcell_of;       // cell of every target, by original id
   int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
-  int ranges_in_lds;         // 1: the window kernel works that table out itself (few bands), range_off is not used
   int bounded;               // 1: neighbours farther than rmax are not wanted (their entries become -1)
   double rmax_window;        // bounded: the widest window stage 2 scans (rmax and a rounding pad)
   double rmax_rdist;         // bounded: sin^2(rmax / 2), the acceptance threshold on the reduced distance
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
   unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
-  double* out_max;           // reference-distance mode: where the largest nearest-neighbour distance goes
   long long* stats;          // [4]
 };
 
@@ -405,59 +403,20 @@ __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
 
 // one thread per descriptor: the targets of the wave and the runs of sources that cover them (stage 1
 // then starts with one load instead of a chain of dependent table look-ups per wave)
-#define AG_KNN_LDS_BANDS 4096  // band tables up to this size are rebuilt in LDS by every block of the window kernel
-__global__ __launch_bounds__(256) void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
+__global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the stages that follow
     a.queue_count[0] = 0;  // stage-2 queue
     a.queue_count[1] = 0;  // float64 re-rank queue
-    a.queue_count[2] = 0;  // blocks of stage 2 that have finished
     if (a.max_bits) *a.max_bits = 0ull;
     if (a.stats) a.stats[0] = a.stats[1] = a.stats[2] = a.stats[3] = 0;
   }
   const int nb = a.tgrid.nb;
-  // Descriptors by ranges: the first descriptor of every band.  With few enough bands every block works the table
-  // out for itself in LDS (a prefix sum over the band populations), which saves the one-block kernel that would
-  // otherwise precede this one and turns the binary searches below into LDS reads.
-  __shared__ int s_range_off[AG_KNN_LDS_BANDS + 1];
-  __shared__ int s_partial[256];
   const int* range_off = a.range_off;
-  if (a.by_range && a.ranges_in_lds) {
-    const int tid = threadIdx.x;
-    for (int b = tid; b < nb; b += 256) {
-      const int cnt = a.tstart[a.tgrid.off[b + 1]] - a.tstart[a.tgrid.off[b]];
-      s_range_off[b] = (cnt + a.range_len - 1) / a.range_len;
-    }
-    __syncthreads();
-    const int per = (nb + 255) / 256;
-    const int b_begin = tid * per, b_end = min(nb, b_begin + per);
-    int sum = 0;
-    for (int b = b_begin; b < b_end; ++b) sum += s_range_off[b];
-    s_partial[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const int v = (tid >= d) ? s_partial[tid - d] : 0;
-      __syncthreads();
-      s_partial[tid] += v;
-      __syncthreads();
-    }
-    int run = s_partial[tid] - sum;
-    for (int b = b_begin; b < b_end; ++b) {
-      const int cnt = s_range_off[b];
-      s_range_off[b] = run;
-      run += cnt;
-    }
-    if (tid == 255) s_range_off[nb] = s_partial[255];
-    __syncthreads();
-    range_off = s_range_off;
-  }
   const int used = a.by_range ? range_off[nb] : a.tgrid.off[nb];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.nwin; i += gridDim.x * blockDim.x) {
-    AgWindow w;
-    w.t0 = w.t1 = 0;
-    w.band = 0;
-    w.pad = 0;
-    w.lon_lo = w.lon_hi = 0.0;
-    w.d[0] = 0;
+    // (the descriptor is written in place: a local copy indexed by the run counter would live in scratch memory)
+    AgWindow* w = out + i;
+    int t0 = 0, t1 = 0;
     int band = 0, col_first = 0, col_last = 0;
     if (i < used) {
       if (a.by_range) {
@@ -468,30 +427,31 @@ __global__ __launch_bounds__(256) void ag_knn_window_kernel(AgKnnArgs a, AgWindo
         }
         band = lo;
         const int b0 = a.tstart[a.tgrid.off[band]], b1 = a.tstart[a.tgrid.off[band + 1]];
-        w.t0 = b0 + a.range_len * (i - range_off[band]);
-        w.t1 = min(w.t0 + a.range_len, b1);
+        t0 = b0 + a.range_len * (i - range_off[band]);
+        t1 = min(t0 + a.range_len, b1);
         // binned targets are ordered by cell, so the cells of the first and the last target bound the rest
-        col_first = a.tcell_of[a.tids[w.t0]] - a.tgrid.off[band];
-        col_last = a.tcell_of[a.tids[w.t1 - 1]] - a.tgrid.off[band];
+        col_first = a.tcell_of[a.tids[t0]] - a.tgrid.off[band];
+        col_last = a.tcell_of[a.tids[t1 - 1]] - a.tgrid.off[band];
       } else {
-        w.t0 = a.tstart[i];
-        w.t1 = a.tstart[i + 1];
-        if (w.t0 < w.t1) {
+        t0 = a.tstart[i];
+        t1 = a.tstart[i + 1];
+        if (t0 < t1) {
           band = ag_band_of_cell(a.tgrid, i);
           col_first = col_last = i - a.tgrid.off[band];
         }
       }
     }
-    if (w.t0 < w.t1) {
+    int nruns = 0;
+    double lon_lo = 0.0, lon_hi = 0.0;
+    if (t0 < t1) {
       const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
-      w.band = band;
-      w.lon_lo = col_first * wlon;
-      w.lon_hi = (col_last + 1) * wlon;
+      lon_lo = col_first * wlon;
+      lon_hi = (col_last + 1) * wlon;
       int n = 0;
       auto keep = [&](int first, int last) {
         if (first < last && n < AG_WIN_RANGES) {
-          w.d[1 + 2 * n] = first;
-          w.d[2 + 2 * n] = last;
+          w->d[1 + 2 * n] = first;
+          w->d[2 + 2 * n] = last;
         }
         if (first < last) ++n;
       };
@@ -499,25 +459,32 @@ __global__ __launch_bounds__(256) void ag_knn_window_kernel(AgKnnArgs a, AgWindo
         // the targets' band belongs to another grid: every source cell within the guaranteed radius of the box
         // the range of targets lies in (its band's latitudes, the longitudes of its cells)
         const double lat_hi = AG_HALF_PI - band * a.tgrid.dlat, lat_lo = lat_hi - a.tgrid.dlat;
-        ag_for_each_range(a.sgrid, a.sstart, lat_lo, lat_hi, w.lon_lo, w.lon_hi, a.rg, keep);
+        ag_for_each_range(a.sgrid, a.sstart, lat_lo, lat_hi, lon_lo, lon_hi, a.rg, keep);
         if (n > AG_WIN_RANGES) {
           // more runs than a descriptor holds: one run over all covered bands (their cells are contiguous
           // in the binned array) -- a superset of the window
           const double pad = 1.0e-7 + 1.0e-6 * a.rg;
           const int b0 = ag_band_of(a.sgrid, lat_hi + a.rg + pad), b1 = ag_band_of(a.sgrid, lat_lo - a.rg - pad);
-          w.d[1] = a.sstart[a.sgrid.off[b0]];
-          w.d[2] = a.sstart[a.sgrid.off[b1 + 1]];
-          n = w.d[2] > w.d[1] ? 1 : 0;
+          const int first = a.sstart[a.sgrid.off[b0]], last = a.sstart[a.sgrid.off[b1 + 1]];
+          w->d[1] = first;
+          w->d[2] = last;
+          n = last > first ? 1 : 0;
         }
-        w.d[0] = n;
+        nruns = n;
       } else {
-        ag_cell_window(a.sgrid, a.sstart, band, w.lon_lo, w.lon_hi, keep);
-        w.d[0] = n <= AG_WIN_RANGES ? n : -1;
+        ag_cell_window(a.sgrid, a.sstart, band, lon_lo, lon_hi, keep);
+        nruns = n <= AG_WIN_RANGES ? n : -1;
       }
     } else {
-      w.t0 = w.t1 = 0;
+      t0 = t1 = 0;
     }
-    out[i] = w;
+    w->d[0] = nruns;
+    w->t0 = t0;
+    w->t1 = t1;
+    w->band = (t0 < t1) ? band : 0;
+    w->pad = 0;
+    w->lon_lo = lon_lo;
+    w->lon_hi = lon_hi;
   }
 }
 
@@ -904,19 +871,13 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       if (rounds) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), static_cast<unsigned long long>(rounds));
     }
   }
-  if (a.out_max != nullptr) {
-    // reference-distance mode: the block that finishes last (every block counts itself in after its own updates of
-    // the running maximum are visible) turns the largest reduced distance into the distance
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const int done = atomicAdd(a.queue_count + 2, 1);
-      if (done == static_cast<int>(gridDim.x) - 1) {
-        const double r = __longlong_as_double(static_cast<long long>(atomicMax(a.max_bits, 0ull)));
-        *a.out_max = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
-      }
-    }
-  }
+}
+
+// (Folding this into the kernel above -- the block that finishes last writes the result -- was measured: 2048 blocks
+// counting themselves in on one word take 36 us, this launch 6.)
+__global__ void ag_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
+  const double r = __longlong_as_double(static_cast<long long>(*max_bits));
+  *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
 }
 
 // cell size for a k-NN search over ns quasi-uniform sources: the disc of radius delta holds
@@ -1089,11 +1050,11 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     a.rmax_rdist = sh * sh;
   }
   a.max_bits = w.max_bits;
-  a.out_max = self_query ? d_out_max : nullptr;
   a.stats = reinterpret_cast<long long*>(d_stats);
 
-  a.ranges_in_lds = (a.by_range && w.tgt.grid.nb <= AG_KNN_LDS_BANDS) ? 1 : 0;
-  if (a.by_range && !a.ranges_in_lds) {
+  // (every block of the window kernel rebuilding this table in LDS, to save the one-block kernel, was measured
+  // slower: 404 blocks x a prologue of dependent loads, 31.6 -> 57.6 us per build for the two searches)
+  if (a.by_range) {
     AG_KERNEL("ag_knn_band_ranges_kernel", ag_knn_band_ranges_kernel, dim3(1), dim3(1024), stream, a);
     AG_LAUNCH_CHECK();
   }
@@ -1110,10 +1071,13 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     default: ag_launch_stage1<AG_KNN_MAX_K + 2>(a, stream); break;
   }
   AG_LAUNCH_CHECK();
-  // (the queue is short as a rule -- the waves stride over it -- so a modest grid; in reference-distance mode its
-  // last block also writes the result)
-  AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(512), dim3(256), stream, a);
+  // (a grid of 512 blocks instead of 2048 was measured slower: the queue of the O1280 decoder holds thousands of targets)
+  AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
   AG_LAUNCH_CHECK();
+  if (self_query) {
+    AG_KERNEL("ag_maxdist_finish_kernel", ag_maxdist_finish_kernel, dim3(1), dim3(1), stream, w.max_bits, d_out_max);
+    AG_LAUNCH_CHECK();
+  }
   if (!self_query && (d_out_dist != nullptr || a.bounded)) {
     AG_KERNEL("ag_knn_dist_kernel", ag_knn_dist_kernel, dim3(ag_blocks(nt * k, 256, 16384)), dim3(256), stream, a);
     AG_LAUNCH_CHECK();
