@@ -255,6 +255,13 @@ extern "C" int ag_binning_build(const float* d_pts, int64_t n, double cell, void
 // ---------------------------------------------------------------------------------------------
 #define AG_TILE 256        // staged sources per wave and pass
 #define AG_WAVES_PER_BLOCK 4
+// The targets stage 1 hands to the float64 re-ranking are appended to queues, one atomic per wave.  Atomics on ONE
+// word are served one after the other by the memory side, about 11 ns each: with a single queue the 7.8 million
+// waves of a 5e8-target search waited 47 ms for their slots (the arithmetic of the kernel takes 9 ms).  Hence many
+// queues, taken in turn by consecutive waves, with their fill words a cache line apart; every queue has room for
+// the targets of all the waves that can use it.
+#define AG_KNN_RQ 256
+#define AG_KNN_RQ_STRIDE 32
 
 struct AgKnnArgs {
   AgGrid sgrid;              // source grid
@@ -273,9 +280,13 @@ struct AgKnnArgs {
   float rg_chord2;           // conservative float32 chord^2 of rg
   int32_t* out_src;          // [nt*k]
   double* out_dist;          // [nt*k] or null
-  int* cand_n;               // [nt] per re-rank queue slot: number of candidates to re-rank in float64
-  int* cand_t;               // [nt] per re-rank queue slot: the binned target
-  int* cand_ids;             // [CAP][nt] candidate ids by queue slot, coalesced per rank
+  int* cand_n;               // [cand_slots] per re-rank queue slot: number of candidates to re-rank in float64
+  int* cand_t;               // [cand_slots] per re-rank queue slot: the binned target
+  int* cand_ids;             // [CAP][cand_slots] candidate ids by queue slot, coalesced per rank
+  int64_t cand_slots;        // slots of the re-rank queues together
+  int* rq_count;             // [rq * AG_KNN_RQ_STRIDE] fill of every re-rank queue
+  int rq;                    // re-rank queues (a power of two); queue q owns the slots [q * rq_cap, (q + 1) * rq_cap)
+  int rq_cap;
   int* queue;                // [nt] targets left to stage 2
   int* queue_count;
   const struct AgWindow* windows;  // [nwin] one descriptor per wave of stage 1: its targets and their source runs
@@ -290,6 +301,34 @@ struct AgKnnArgs {
   int self_query;            // 1: reference-distance mode (sources == targets, k == 2)
   unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
   long long* stats;          // [4]
+  AgKnnArgs* device_copy;    // this structure in device memory, written by the window kernel (see AgKnnHot)
+};
+
+// What a wave of stage 1 reads on its usual path.  The arguments of a kernel sit in scalar registers for its whole
+// run, and the two grids of AgKnnArgs pushed those of the candidate loop out into lanes of vector registers (a
+// hundred lane writes per wave before the first useful instruction); the grids are only needed by a window with
+// more runs than its descriptor holds, which reads them from `full`, the copy the window kernel left in device memory.
+struct AgKnnHot {
+  int* rq_count;
+  int64_t cand_slots;
+  int rq, rq_cap;
+  const struct AgWindow* windows;
+  const float4* spts;
+  const float4* tpts;
+  const int* tids;
+  const float2* tgt;
+  int32_t* out_src;
+  int* cand_n;
+  int* cand_t;
+  int* cand_ids;
+  int* queue;
+  int* queue_count;
+  const AgKnnArgs* full;
+  int64_t nt;
+  int nwin;
+  int k;
+  int self_query;
+  float rg_chord2;
 };
 
 // Largest candidate list that is re-ranked in float64 by one thread (ag_knn_resolve_kernel, registers
@@ -362,11 +401,15 @@ __device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __res
 // The work of one wave of stage 1: the binned targets [t0, t1) -- all in latitude band `band`, with
 // longitudes inside [lon_lo, lon_hi] -- and up to AG_WIN_RANGES half-open runs of binned sources that
 // hold every source within the guaranteed radius of any of them.
-// d[0] = number of runs (-1: too many, the wave enumerates them itself), d[1 + 2i], d[2 + 2i] = run i.
+// The runs laid end to end are the wave's tile: slot s of the tile is binned source s + d[1 + 2i] for the run i
+// with d[2 + 2(i-1)] <= s < d[2 + 2i]  (d[1 + 2i] = first source of run i minus the slots before it, d[2 + 2i] =
+// slots up to and including run i), so that every lane finds the sources of its slots without a loop over the
+// runs and all loads of a tile are in flight together.  d[0] = number of runs (-1: too many, the wave enumerates
+// them itself); total = slots of all runs (-1 when the runs are not listed).
 #define AG_WIN_RANGES 9
 struct __attribute__((aligned(32))) AgWindow {
   int d[20];
-  int t0, t1, band, pad;
+  int t0, t1, band, total;
   double lon_lo, lon_hi;
 };
 
@@ -406,10 +449,13 @@ __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
 __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the stages that follow
     a.queue_count[0] = 0;  // stage-2 queue
-    a.queue_count[1] = 0;  // float64 re-rank queue
+    a.queue_count[1] = 0;
+    *a.device_copy = a;
     if (a.max_bits) *a.max_bits = 0ull;
     if (a.stats) a.stats[0] = a.stats[1] = a.stats[2] = a.stats[3] = 0;
   }
+  if (blockIdx.x == 0)  // fill of the float64 re-rank queues
+    for (int q = threadIdx.x; q < a.rq; q += blockDim.x) a.rq_count[q * AG_KNN_RQ_STRIDE] = 0;
   const int nb = a.tgrid.nb;
   const int* range_off = a.range_off;
   const int used = a.by_range ? range_off[nb] : a.tgrid.off[nb];
@@ -441,7 +487,7 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
         }
       }
     }
-    int nruns = 0;
+    int nruns = 0, total = 0;
     double lon_lo = 0.0, lon_hi = 0.0;
     if (t0 < t1) {
       const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
@@ -450,10 +496,13 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
       int n = 0;
       auto keep = [&](int first, int last) {
         if (first < last && n < AG_WIN_RANGES) {
-          w->d[1 + 2 * n] = first;
-          w->d[2 + 2 * n] = last;
+          w->d[1 + 2 * n] = first - total;
+          w->d[2 + 2 * n] = total + (last - first);
         }
-        if (first < last) ++n;
+        if (first < last) {
+          ++n;
+          total += last - first;
+        }
       };
       if (a.foreign_targets) {
         // the targets' band belongs to another grid: every source cell within the guaranteed radius of the box
@@ -467,8 +516,9 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
           const int b0 = ag_band_of(a.sgrid, lat_hi + a.rg + pad), b1 = ag_band_of(a.sgrid, lat_lo - a.rg - pad);
           const int first = a.sstart[a.sgrid.off[b0]], last = a.sstart[a.sgrid.off[b1 + 1]];
           w->d[1] = first;
-          w->d[2] = last;
+          w->d[2] = last - first;
           n = last > first ? 1 : 0;
+          total = n ? last - first : 0;
         }
         nruns = n;
       } else {
@@ -482,26 +532,108 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
     w->t0 = t0;
     w->t1 = t1;
     w->band = (t0 < t1) ? band : 0;
-    w->pad = 0;
+    w->total = nruns >= 0 ? total : -1;
     w->lon_lo = lon_lo;
     w->lon_hi = lon_hi;
   }
 }
 
+// Stage 1 for a window that does not fit one tile, or whose runs its descriptor does not list (a handful of
+// windows of a search, if any): tile after tile, sorted inserts with ids.  Kept out of line, behind a call: inlined, its
+// loops and the grid it reads cost the usual path scalar registers for the whole run of the kernel.  Every value
+// read from the descriptor is the same in all lanes; `out_d` / `out_i` receive the CAP best (float32 chord^2, id).
 template <int CAP>
-__global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(AgKnnArgs a) {
+__device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* __restrict__ full,
+                                                             const AgWindow* __restrict__ wp, float4* tile, float tx,
+                                                             float ty, float tz, float* out_d, int* out_i) {
+  const int lane = ag_lane();
+  const float4* __restrict__ spts = full->spts;
+  float bd[CAP];
+  int bi[CAP];
+#pragma unroll
+  for (int j = 0; j < CAP; ++j) {
+    bd[j] = 3.0e38f;
+    bi[j] = -1;
+  }
+  int fill = 0;
+  auto scan_tile = [&](int count) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = 0; j < count; ++j) {
+      const float4 s = tile[j];
+      const float dx = s.x - tx, dy = s.y - ty, dz = s.z - tz;
+      const float d = dx * dx + dy * dy + dz * dz;
+      ag_topk_insert<CAP>(bd, bi, d, __float_as_int(s.w));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto stage_run = [&](int first_pos, int last_pos) {
+    int pos = first_pos;
+    while (pos < last_pos) {
+      const int take = min(last_pos - pos, AG_TILE - fill);
+      for (int i = lane; i < take; i += 64) tile[fill + i] = spts[pos + i];
+      fill += take;
+      pos += take;
+      if (fill == AG_TILE) {
+        scan_tile(fill);
+        fill = 0;
+      }
+    }
+  };
+  const int nruns = __builtin_amdgcn_readfirstlane(wp->d[0]);
+  if (nruns >= 0) {
+    int before = 0;
+    for (int r = 0; r < nruns; ++r) {
+      const int off = __builtin_amdgcn_readfirstlane(wp->d[1 + 2 * r]);
+      const int upto = __builtin_amdgcn_readfirstlane(wp->d[2 + 2 * r]);
+      stage_run(off + before, off + upto);
+      before = upto;
+    }
+  } else {
+    ag_cell_window(full->sgrid, full->sstart, __builtin_amdgcn_readfirstlane(wp->band), wp->lon_lo, wp->lon_hi, stage_run);
+  }
+  if (fill > 0) scan_tile(fill);
+#pragma unroll
+  for (int j = 0; j < CAP; ++j) {
+    out_d[j] = bd[j];
+    out_i[j] = bi[j];
+  }
+}
+
+// K = the number of neighbours when it is one of the small values instantiated below (the comparisons with it then
+// cost nothing), 0 = read it from the arguments.
+template <int CAP, int K>
+__global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(AgKnnHot a) {
   __shared__ float4 tile_all[AG_WAVES_PER_BLOCK][AG_TILE];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = ag_lane();
   float4* tile = tile_all[wave];
-  const int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * AG_WAVES_PER_BLOCK + wave);
+  int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * AG_WAVES_PER_BLOCK + wave);
   if (wi >= a.nwin) return;
-  const AgWindow win = a.windows[wi];
-  const int t0 = win.t0, t1 = win.t1;
-  if (t0 >= t1) return;
-  const int k = a.k;
+  const int k = K > 0 ? K : a.k;
 
-  for (int tb = t0; tb < t1; tb += 64) {
+  for (int pass = 0;; ++pass) {
+    // A descriptor nearly always holds one pass of targets.  It is read inside the loop, behind an index made
+    // opaque: hoisted out, everything derived from it stays in scalar registers for the whole pass, and those
+    // run out.  (Read through the constant address space: descriptors are written by an earlier launch, and only
+    // loads the compiler knows to be unclobbered become scalar loads -- inside this loop, after the stores of a
+    // previous pass, it cannot know.)
+    asm volatile("" : "+v"(wi));
+    wi = __builtin_amdgcn_readfirstlane(wi);
+    typedef const int __attribute__((address_space(4))) * AgScalarInts;
+    const AgScalarInts wq = (AgScalarInts)(reinterpret_cast<uintptr_t>(a.windows + wi));
+    struct {
+      int d[2 * AG_WIN_RANGES + 1];
+      int total;
+    } win;
+#pragma unroll
+    for (int i = 0; i < 2 * AG_WIN_RANGES + 1; ++i) win.d[i] = wq[i];
+    const int t1 = wq[offsetof(AgWindow, t1) / sizeof(int)];
+    const int tb = wq[offsetof(AgWindow, t0) / sizeof(int)] + 64 * pass;
+    win.total = wq[offsetof(AgWindow, total) / sizeof(int)];
+    if (tb >= t1) break;
     const int ti = tb + lane;
     const bool active = ti < t1;
     int tid = -1;
@@ -529,23 +661,35 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     // key is one v_min_u32 plus CAP-1 v_med3_u32, with no branch and no id bookkeeping; the ids are
     // read back from the tile at the end.  The tag costs 255 ulp of resolution, which the
     // classification below accounts for (ag_chord2_err_tagged).
-    int win_total = -1;
-    if (win.d[0] >= 0) {
-      win_total = 0;
-#pragma unroll
-      for (int r = 0; r < AG_WIN_RANGES; ++r)
-        if (r < win.d[0]) win_total += win.d[2 + 2 * r] - win.d[1 + 2 * r];
-    }
+    const int win_total = win.total;
     const bool tagged = win_total >= 0 && win_total <= AG_TILE;
     if (tagged) {
-      int fillt = 0;
+      // every lane loads the sources of its slots (lane, lane + 64, ...): the loads of the whole tile -- and the
+      // one of the target above -- are in flight together, one wait for all of them
+      static_assert(AG_TILE == 256, "four slots per lane");
+      auto load_slot = [&](int slot) {
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < win_total) {
+          int off = win.d[1];
 #pragma unroll
-      for (int r = 0; r < AG_WIN_RANGES; ++r) {
-        if (r < win.d[0]) {
-          const int first_pos = win.d[1 + 2 * r], take = win.d[2 + 2 * r] - first_pos;
-          for (int i = lane; i < take; i += 64) tile[fillt + i] = a.spts[first_pos + i];
-          fillt += take;
+          for (int r = 1; r < AG_WIN_RANGES; ++r)
+            if (r < win.d[0]) off = (slot >= win.d[2 * r]) ? win.d[1 + 2 * r] : off;
+          rec = a.spts[slot + off];
         }
+        return rec;
+      };
+      const float4 rec0 = load_slot(lane);
+      float4 rec1 = make_float4(0.f, 0.f, 0.f, 0.f), rec2 = rec1, rec3 = rec1;
+      if (win_total > 64) {
+        rec1 = load_slot(lane + 64);
+        rec2 = load_slot(lane + 128);
+        rec3 = load_slot(lane + 192);
+      }
+      if (lane < win_total) tile[lane] = rec0;
+      if (win_total > 64) {
+        if (lane + 64 < win_total) tile[lane + 64] = rec1;
+        if (lane + 128 < win_total) tile[lane + 128] = rec2;
+        if (lane + 192 < win_total) tile[lane + 192] = rec3;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -553,11 +697,11 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       unsigned kb[CAP];
 #pragma unroll
       for (int j = 0; j < CAP; ++j) kb[j] = 0xffffffffu;
-      for (int j = 0; j < fillt; ++j) {
-        const float4 s = tile[j];
+      auto chord2 = [&](const float4& s) {
         const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
-        const float d = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
-        const unsigned x = (__float_as_uint(d) & 0xffffff00u) | static_cast<unsigned>(j);
+        return __float_as_uint(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+      };
+      auto insert = [&](unsigned x) {
         unsigned prev = kb[0];
         kb[0] = min(prev, x);
 #pragma unroll
@@ -566,54 +710,41 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
           kb[i] = max(min(prev, cur), min(max(prev, cur), x));  // median of three
           prev = cur;
         }
+      };
+      // four candidates per turn: their slots travel as the four bytes of one register, and one byte permute
+      // per candidate puts the slot under the upper three bytes of the chord^2 (one add per four candidates
+      // instead of an and + or per candidate)
+      unsigned slots = 0x03020100u;
+      int j = 0;
+      for (; j + 4 <= win_total; j += 4) {
+        const float4 s0 = tile[j], s1 = tile[j + 1], s2 = tile[j + 2], s3 = tile[j + 3];
+        insert(__builtin_amdgcn_perm(chord2(s0), slots, 0x07060500u));
+        insert(__builtin_amdgcn_perm(chord2(s1), slots, 0x07060501u));
+        insert(__builtin_amdgcn_perm(chord2(s2), slots, 0x07060502u));
+        insert(__builtin_amdgcn_perm(chord2(s3), slots, 0x07060503u));
+        slots += 0x04040404u;
       }
+      for (; j < win_total; ++j) insert((chord2(tile[j]) & 0xffffff00u) | static_cast<unsigned>(j));
+#pragma unroll
+      for (int j2 = 0; j2 < CAP; ++j2) {
+        if (kb[j2] != 0xffffffffu) {
+          bd[j2] = __uint_as_float(kb[j2] & 0xffffff00u);
+          bi[j2] = __float_as_int(tile[kb[j2] & 0xffu].w);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!tagged) {
+      float far_d[CAP];
+      int far_i[CAP];
+      ag_knn_scan_general<CAP>(a.full, a.windows + wi, tile, tu.x, tu.y, tu.z, far_d, far_i);
 #pragma unroll
       for (int j = 0; j < CAP; ++j) {
-        if (kb[j] != 0xffffffffu) {
-          bd[j] = __uint_as_float(kb[j] & 0xffffff00u);
-          bi[j] = __float_as_int(tile[kb[j] & 0xffu].w);
-        }
+        bd[j] = far_d[j];
+        bi[j] = far_i[j];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
-    int fill = 0;
-    auto scan_tile = [&](int count) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int j = 0; j < count; ++j) {
-        const float4 s = tile[j];
-        const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
-        const float d = dx * dx + dy * dy + dz * dz;
-        ag_topk_insert<CAP>(bd, bi, d, __float_as_int(s.w));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    };
-    auto stage_run = [&](int first_pos, int last_pos) {
-      int pos = first_pos;
-      while (pos < last_pos) {
-        const int take = min(last_pos - pos, AG_TILE - fill);
-        for (int i = lane; i < take; i += 64) tile[fill + i] = a.spts[pos + i];
-        fill += take;
-        pos += take;
-        if (fill == AG_TILE) {
-          scan_tile(fill);
-          fill = 0;
-        }
-      }
-    };
-    if (tagged) {
-      // done above
-    } else if (win.d[0] >= 0) {
-#pragma unroll
-      for (int r = 0; r < AG_WIN_RANGES; ++r)
-        if (r < win.d[0]) stage_run(win.d[1 + 2 * r], win.d[2 + 2 * r]);
-    } else {
-      ag_cell_window(a.sgrid, a.sstart, win.band, win.lon_lo, win.lon_hi, stage_run);
-    }
-    if (fill > 0) scan_tile(fill);
 
     // ---- classify -------------------------------------------------------------------------
     // Let dk be the float32 chord^2 of the k-th entry and ek its error bound.  Every candidate whose
@@ -672,27 +803,33 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
           a.cand_t[ti] = ti;
           if (rec) {
 #pragma unroll
-            for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.nt + ti] = bi[j];
+            for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + ti] = bi[j];
           }
         }
       } else if (m) {
         int base = 0;
         const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        if (lane == leader) base = atomicAdd(a.queue_count + 1, __popcll(m));
-        base = __shfl(base, leader, 64);
-        if (rec) {
-          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        const int q = wi & (a.rq - 1);
+        if (lane == leader) base = atomicAdd(a.rq_count + q * AG_KNN_RQ_STRIDE, __popcll(m));
+        base = __shfl(base, leader, 64) + q * a.rq_cap;
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (rec && slot < a.cand_slots) {  // (a queue holds every target that can reach it: the bound only guards the store)
           a.cand_n[slot] = c1 + 1;
           a.cand_t[slot] = ti;
 #pragma unroll
-          for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.nt + slot] = bi[j];
+          for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + slot] = bi[j];
         }
       }
     }
-    if (queued) {
-      const int slot = atomicAdd(a.queue_count, 1);
-      a.queue[slot] = tid;
+    const unsigned long long mq = __ballot(queued);
+    if (mq) {  // stage-2 queue: one atomic per wave
+      int base = 0;
+      const int leader = __ffsll(static_cast<long long>(mq)) - 1;
+      if (lane == leader) base = atomicAdd(a.queue_count, __popcll(mq));
+      base = __shfl(base, leader, 64);
+      if (queued) a.queue[base + __popcll(mq & ((1ull << lane) - 1ull))] = tid;
     }
+    if (tb + 64 >= t1) break;
   }
 }
 
@@ -705,8 +842,15 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
   __shared__ double sh[4];
   double my_max = 0.0;
   const int k = a.k;
-  const int64_t nslots = a.self_query ? a.nt : a.queue_count[1];
-  for (int64_t slot = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; slot < nslots; slot += int64_t(gridDim.x) * blockDim.x) {
+  // Consecutive blocks take consecutive queues (a set queried against itself has one queue, with a slot per
+  // target): the entries of a queue sit in its first blocks, and blocks go to the dies of the GPU in turn -- a grid
+  // with the queue as its second dimension put every block that has work on one die.
+  const int queues = a.self_query ? 1 : a.rq;
+  const int q = blockIdx.x % queues, part = blockIdx.x / queues, parts = gridDim.x / queues;
+  const int64_t first_slot = a.self_query ? 0 : int64_t(q) * a.rq_cap;
+  const int64_t nslots = a.self_query ? a.nt : a.rq_count[q * AG_KNN_RQ_STRIDE];
+  for (int64_t at = part * int64_t(blockDim.x) + threadIdx.x; at < nslots; at += int64_t(parts) * blockDim.x) {
+    const int64_t slot = first_slot + at;
     const int n = a.cand_n[slot];
     if (n == 0) continue;
     const int ti = a.cand_t[slot];
@@ -719,7 +863,7 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
       rr[j] = 1.0e300;
       bi[j] = 0x7fffffff;
       if (j < n) {
-        bi[j] = a.cand_ids[static_cast<int64_t>(j) * a.nt + slot];
+        bi[j] = a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + slot];
         const float2 p = a.src[bi[j]];
         rr[j] = ag_rdist(tp.x, tp.y, p.x, p.y);
       }
@@ -938,7 +1082,11 @@ struct AgKnnWs {
   int* cand_n;
   int* cand_t;
   int* cand_ids;
+  int64_t cand_slots;
+  int rq_cap;
+  int* rq_count;
   struct AgWindow* windows;
+  struct AgKnnArgs* args_copy;
 };
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
@@ -969,13 +1117,23 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   int* queue = c.take<int>(nt);
   int* queue_count = c.take<int>(4);
   unsigned long long* max_bits = c.take<unsigned long long>(2);
-  int* cand_n = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
-  int* cand_t = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt) : nullptr;
-  int* cand_ids = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(nt * cap) : nullptr;
   const int64_t win_a = ag_knn_windows_ub(nt, nb_t, foreign ? 1 : tmult), win_b = ag_knn_windows_ub(nt, nb, 1, AG_KNN_SELF_RANGE);
-  AgWindow* windows = c.take<AgWindow>((win_a > win_b ? win_a : win_b) + 1);
+  const int64_t win_ub = (win_a > win_b ? win_a : win_b) + 1;
+  // slots of the re-rank queues: by ranges (at most 64 targets per descriptor) every queue holds the targets of its
+  // share of the descriptors; otherwise there is one queue, of all targets
+  const int64_t by_range_a = ag_knn_windows_ub(nt, nb_t, 1), by_range_b = ag_knn_windows_ub(nt, nb, 1, AG_KNN_SELF_RANGE);
+  const int64_t by_range_ub = (by_range_a > by_range_b ? by_range_a : by_range_b) + 1;
+  const int64_t per_queue = ((by_range_ub + AG_KNN_RQ - 1) / AG_KNN_RQ) * 64;
+  const int64_t cand_slots = per_queue * AG_KNN_RQ > nt ? per_queue * AG_KNN_RQ : nt;
+  int* cand_n = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(cand_slots) : nullptr;
+  int* cand_t = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(cand_slots) : nullptr;
+  int* cand_ids = cap <= AG_KNN_RESOLVE_CAP ? c.take<int>(cand_slots * cap) : nullptr;
+  int* rq_count = c.take<int>(AG_KNN_RQ * AG_KNN_RQ_STRIDE);
+  AgWindow* windows = c.take<AgWindow>(win_ub);
   int* range_off = c.take<int>((nb_t > nb ? nb_t : nb) + 1);
+  AgKnnArgs* args_copy = c.take<AgKnnArgs>(1);
   if (w) {
+    w->args_copy = args_copy;
     w->windows = windows;
     w->range_off = range_off;
     w->tmult = (same_set || foreign) ? 1 : tmult;  // (by ranges of the source binning itself / of the kept binning)
@@ -986,17 +1144,59 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
     w->cand_n = cand_n;
     w->cand_t = cand_t;
     w->cand_ids = cand_ids;
+    w->cand_slots = cand_slots;
+    w->rq_cap = static_cast<int>(per_queue);
+    w->rq_count = rq_count;
   }
   return AG_OK;
 }
 
+template <int CAP, int K>
+static void ag_launch_stage1_k(const AgKnnArgs& a, hipStream_t stream) {
+  const int blocks = ag_blocks(a.nwin, AG_WAVES_PER_BLOCK);
+  AgKnnHot h;
+  h.windows = a.windows;
+  h.spts = a.spts;
+  h.tpts = a.tpts;
+  h.tids = a.tids;
+  h.tgt = a.tgt;
+  h.out_src = a.out_src;
+  h.cand_n = a.cand_n;
+  h.cand_t = a.cand_t;
+  h.cand_ids = a.cand_ids;
+  h.cand_slots = a.cand_slots;
+  h.rq_count = a.rq_count;
+  h.rq = a.rq;
+  h.rq_cap = a.rq_cap;
+  h.queue = a.queue;
+  h.queue_count = a.queue_count;
+  h.full = a.device_copy;
+  h.nt = a.nt;
+  h.nwin = a.nwin;
+  h.k = a.k;
+  h.self_query = a.self_query;
+  h.rg_chord2 = a.rg_chord2;
+  AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", (ag_knn_cell_kernel<CAP, K>), dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, h);
+  if constexpr (CAP <= AG_KNN_RESOLVE_CAP) {
+    const int64_t per_queue = a.self_query ? a.nt : a.rq_cap;
+    const int queues = a.self_query ? 1 : a.rq;
+    AG_KERNEL("ag_knn_resolve_kernel", ag_knn_resolve_kernel<CAP>, dim3(ag_blocks(per_queue, 256, 8192 / queues) * queues), dim3(256), stream, a);
+  }
+}
+
+// the instance of stage 1 with the number of neighbours compiled in, where there is one
 template <int CAP>
 static void ag_launch_stage1(const AgKnnArgs& a, hipStream_t stream) {
-  const int blocks = ag_blocks(a.nwin, AG_WAVES_PER_BLOCK);
-  AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", ag_knn_cell_kernel<CAP>, dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, a);
-  if constexpr (CAP <= AG_KNN_RESOLVE_CAP) {
-    AG_KERNEL("ag_knn_resolve_kernel", ag_knn_resolve_kernel<CAP>, dim3(ag_blocks(a.nt, 256, 8192)), dim3(256), stream, a);
+  if constexpr (CAP == 3) {
+    if (a.k == 1) return ag_launch_stage1_k<CAP, 1>(a, stream);
+  } else if constexpr (CAP == 5) {
+    if (a.k == 2) return ag_launch_stage1_k<CAP, 2>(a, stream);
+    if (a.k == 3) return ag_launch_stage1_k<CAP, 3>(a, stream);
+  } else if constexpr (CAP == 8) {
+    if (a.k == 2) return ag_launch_stage1_k<CAP, 2>(a, stream);
+    if (a.k == 4) return ag_launch_stage1_k<CAP, 4>(a, stream);
   }
+  ag_launch_stage1_k<CAP, 0>(a, stream);
 }
 
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
@@ -1017,7 +1217,9 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.sstart = w.src.cell_start;
   a.tids = w.tgt.ids;
   a.foreign_targets = kept_tgt.buffer != nullptr ? 1 : 0;
-  a.tpts = a.foreign_targets ? w.tgt.pts : nullptr;
+  // binned records of the targets (unit vector, id): a kept binning has them, and so has a set queried against
+  // itself, whose targets are the binned sources
+  a.tpts = (a.foreign_targets || (d_src == d_tgt && ns == nt)) ? w.tgt.pts : nullptr;
   a.tstart = w.tgt.cell_start;
   a.tgt = reinterpret_cast<const float2*>(d_tgt);
   a.src = reinterpret_cast<const float2*>(d_src);
@@ -1034,11 +1236,15 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.cand_n = w.cand_n;
   a.cand_t = w.cand_t;
   a.cand_ids = w.cand_ids;
+  a.cand_slots = w.cand_slots;
+  a.rq_count = w.rq_count;
   a.queue = w.queue;
   a.queue_count = w.queue_count;
   a.windows = w.windows;
   a.by_range = ag_knn_by_range(w.tmult) ? 1 : 0;
   a.range_len = w.range_len;
+  a.rq = a.by_range ? AG_KNN_RQ : 1;
+  a.rq_cap = a.by_range ? w.rq_cap : static_cast<int>(nt);
   a.nwin = static_cast<int>(ag_knn_windows_ub(nt, w.tgt.grid.nb, w.tmult, w.range_len));
   a.tcell_of = w.tgt.cell_of;
   a.range_off = w.range_off;
@@ -1051,6 +1257,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   }
   a.max_bits = w.max_bits;
   a.stats = reinterpret_cast<long long*>(d_stats);
+  a.device_copy = w.args_copy;
 
   // (every block of the window kernel rebuilding this table in LDS, to save the one-block kernel, was measured
   // slower: 404 blocks x a prologue of dependent loads, 31.6 -> 57.6 us per build for the two searches)
@@ -1166,7 +1373,7 @@ extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, v
 // Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends.
 // In host code the array's name is only a handle for hipGetSymbolAddress: the address that kernels, copies and
 // fills may use is the one that call returns for the current device, looked up once per device and kept.
-#define AG_STATIC_SCRATCH_BYTES (size_t(40) << 20)
+#define AG_STATIC_SCRATCH_BYTES (size_t(48) << 20)
 static __device__ __align__(256) unsigned char ag_static_scratch[AG_STATIC_SCRATCH_BYTES];
 
 #define AG_STATIC_MAX_DEVICES 64

@@ -80,7 +80,7 @@ int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, 
 
 /* ag_nn_maxdist without a workspace argument, for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
- * reference.  The scratch memory is an array built into the library (40 MiB on every GPU the library runs on,
+ * reference.  The scratch memory is an array built into the library (48 MiB on every GPU the library runs on,
  * held until the process ends), which bounds the input: 2 <= n <= AG_NN_MAXDIST_STATIC_MAX_N, more is refused
  * with an error.  Nothing is allocated or freed, by the library or by a routine it calls; the first call on a
  * device looks the array's address up (hipGetSymbolAddress), so make that call outside a capture.  Same
