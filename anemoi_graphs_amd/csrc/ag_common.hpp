@@ -232,6 +232,75 @@ __device__ __forceinline__ float ag_chord2_err_tagged(float c2) {
   return 1.0000003e-6f * __builtin_amdgcn_sqrtf(c2) + 3.2e-5f * c2 + 4.0e-13f;
 }
 
+// The window of a box of targets (or of a single point): the bands b0..b1 it covers and, unless `full` (every
+// cell of those bands), the longitude interval [lo, hi] (unwrapped: it may leave [0, 2 pi] on either side).
+struct AgPointWindow {
+  int b0, b1;
+  bool full;
+  double lo, hi;
+};
+
+// Window of every point within angular distance R of any target in the box lat in [lat_lo, lat_hi], wrapped
+// longitude in [lon_lo, lon_hi] (lon_lo <= lon_hi, both in [0, 2pi]).
+__device__ __forceinline__ AgPointWindow ag_box_window(const AgGrid& g, double lat_lo, double lat_hi, double lon_lo,
+                                                       double lon_hi, double R) {
+  AgPointWindow w;
+  const double pad = 1.0e-7 + 1.0e-6 * R;
+  w.b0 = ag_band_of(g, lat_hi + R + pad);
+  w.b1 = ag_band_of(g, lat_lo - R - pad);
+  const double phit = fmax(fabs(lat_lo), fabs(lat_hi));
+  w.full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
+  w.lo = 0.0;
+  w.hi = 0.0;
+  if (!w.full) {
+    const double q = ag_sin_f64(R) / ag_cos_f64(phit);
+    if (q >= 1.0) {
+      w.full = true;
+    } else {
+      const double delta = asin(q) * (1.0 + 1.0e-6) + pad;
+      w.lo = lon_lo - delta;
+      w.hi = lon_hi + delta;
+      if (w.hi - w.lo >= AG_TWO_PI) w.full = true;
+    }
+  }
+  return w;
+}
+
+__device__ __forceinline__ AgPointWindow ag_point_window(const AgGrid& g, double lat, double lonw, double R) {
+  return ag_box_window(g, lat, lat, lonw, lonw, R);
+}
+
+// Cells [c_first, c_last) of a band of nc cells that the window covers: its first run, or its second one (empty
+// unless the longitude interval wraps).
+__device__ __forceinline__ void ag_window_cells(const AgPointWindow& w, int nc, bool second, int* c_first, int* c_last) {
+  // 32-bit cell numbers: a band has far fewer than 2^29 cells, and lo, hi lie within a few turns of [0, 2 pi].
+  // (64-bit integers here cost an emulated conversion and an emulated remainder per run -- most of the window
+  // kernels' instructions.)  The interval starts within one turn of [0, 2 pi) whenever the longitudes given are
+  // wrapped, so the remainder is an addition or a subtraction; anything else takes the division.
+  const double wd = nc * AG_INV_TWO_PI;
+  const int ca = static_cast<int>(floor(w.lo * wd));
+  const int cb = static_cast<int>(floor(w.hi * wd));
+  const int len = cb - ca + 1;
+  *c_first = 0;
+  *c_last = 0;
+  if (w.full || nc == 1 || len >= nc) {
+    *c_last = second ? 0 : nc;
+  } else {
+    int cam = ca < 0 ? ca + nc : (ca >= nc ? ca - nc : ca);
+    if (cam < 0 || cam >= nc) {
+      cam = ca % nc;
+      if (cam < 0) cam += nc;
+    }
+    const int end = cam + len;
+    if (!second) {
+      *c_first = cam;
+      *c_last = min(end, nc);
+    } else if (end > nc) {
+      *c_last = end - nc;
+    }
+  }
+}
+
 // Enumerate the runs of binned points that can hold a point within angular distance R of any
 // target in the box lat in [lat_lo, lat_hi], wrapped longitude in [lon_lo, lon_hi] (lon_lo <=
 // lon_hi, both in [0, 2pi]).  f(first, last) receives half-open ranges into the binned array.
@@ -239,46 +308,15 @@ __device__ __forceinline__ float ag_chord2_err_tagged(float c2) {
 template <class F>
 __device__ __forceinline__ void ag_for_each_range(const AgGrid& g, const int* __restrict__ cell_start, double lat_lo,
                                                   double lat_hi, double lon_lo, double lon_hi, double R, F&& f) {
-  const double pad = 1.0e-7 + 1.0e-6 * R;
-  const double top = lat_hi + R + pad, bot = lat_lo - R - pad;
-  const int b0 = ag_band_of(g, top), b1 = ag_band_of(g, bot);
-  const double phit = fmax(fabs(lat_lo), fabs(lat_hi));
-  bool full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
-  double lo = 0.0, hi = 0.0;
-  if (!full) {
-    const double q = ag_sin_f64(R) / ag_cos_f64(phit);
-    if (q >= 1.0) {
-      full = true;
-    } else {
-      const double delta = asin(q) * (1.0 + 1.0e-6) + pad;
-      lo = lon_lo - delta;
-      hi = lon_hi + delta;
-      if (hi - lo >= AG_TWO_PI) full = true;
-    }
-  }
-  for (int b = b0; b <= b1; ++b) {
+  const AgPointWindow w = ag_box_window(g, lat_lo, lat_hi, lon_lo, lon_hi, R);
+  for (int b = w.b0; b <= w.b1; ++b) {
     const int nc = g.ncols[b];
     const int base = g.off[b];
-    if (full || nc == 1) {
-      f(cell_start[base], cell_start[base + nc]);
-      continue;
-    }
-    const double w = nc * AG_INV_TWO_PI;
-    const long long ca = static_cast<long long>(floor(lo * w));
-    const long long cb = static_cast<long long>(floor(hi * w));
-    const long long len = cb - ca + 1;
-    if (len >= nc) {
-      f(cell_start[base], cell_start[base + nc]);
-      continue;
-    }
-    int cam = static_cast<int>(ca % nc);
-    if (cam < 0) cam += nc;
-    if (cam + len <= nc) {
-      f(cell_start[base + cam], cell_start[base + cam + static_cast<int>(len)]);
-    } else {
-      f(cell_start[base + cam], cell_start[base + nc]);
-      f(cell_start[base], cell_start[base + cam + static_cast<int>(len) - nc]);
-    }
+    int c_first, c_last;
+    ag_window_cells(w, nc, false, &c_first, &c_last);
+    f(cell_start[base + c_first], cell_start[base + c_last]);
+    ag_window_cells(w, nc, true, &c_first, &c_last);
+    if (c_last > c_first) f(cell_start[base + c_first], cell_start[base + c_last]);
   }
 }
 
@@ -290,48 +328,16 @@ __device__ __forceinline__ int ag_lane() { return threadIdx.x & 63; }
 // dependent loads of all bands overlap.  Returns the total number of runs (wave-uniform).
 __device__ __forceinline__ int ag_lane_range(const AgGrid& g, const int* __restrict__ cell_start, double lat,
                                              double lonw, double R, int j, int* first, int* last) {
-  const double pad = 1.0e-7 + 1.0e-6 * R;
-  const int b0 = ag_band_of(g, lat + R + pad), b1 = ag_band_of(g, lat - R - pad);
-  const double phit = fabs(lat);
-  bool full = (phit + R + pad >= AG_HALF_PI) || (R >= AG_HALF_PI);
-  double lo = 0.0, hi = 0.0;
-  if (!full) {
-    const double q = ag_sin_f64(R) / ag_cos_f64(phit);
-    if (q >= 1.0) {
-      full = true;
-    } else {
-      const double delta = asin(q) * (1.0 + 1.0e-6) + pad;
-      lo = lonw - delta;
-      hi = lonw + delta;
-      if (hi - lo >= AG_TWO_PI) full = true;
-    }
-  }
-  const int nruns = 2 * (b1 - b0 + 1);
+  const AgPointWindow w = ag_point_window(g, lat, lonw, R);
+  const int nruns = 2 * (w.b1 - w.b0 + 1);
   *first = 0;
   *last = 0;
   if (j < nruns) {
-    const int b = b0 + (j >> 1);
-    const bool second = (j & 1) != 0;
+    const int b = w.b0 + (j >> 1);
     const int nc = g.ncols[b];
     const int base = g.off[b];
-    const double w = nc * AG_INV_TWO_PI;
-    const long long ca = static_cast<long long>(floor(lo * w));
-    const long long cb = static_cast<long long>(floor(hi * w));
-    const long long len = cb - ca + 1;
-    int c_first = 0, c_last = 0;  // cell range [c_first, c_last) inside the band
-    if (full || nc == 1 || len >= nc) {
-      c_last = second ? 0 : nc;
-    } else {
-      int cam = static_cast<int>(ca % nc);
-      if (cam < 0) cam += nc;
-      const int end = cam + static_cast<int>(len);
-      if (!second) {
-        c_first = cam;
-        c_last = min(end, nc);
-      } else if (end > nc) {
-        c_last = end - nc;
-      }
-    }
+    int c_first, c_last;
+    ag_window_cells(w, nc, (j & 1) != 0, &c_first, &c_last);
     if (c_last > c_first) {
       *first = cell_start[base + c_first];
       *last = cell_start[base + c_last];

@@ -369,32 +369,20 @@ template <class F>
 __device__ __forceinline__ void ag_cell_window(const AgGrid& g, const int* __restrict__ cell_start, int band,
                                                double lon_lo, double lon_hi, F&& f) {
   const double delta = g.win[band];
-  const bool full = delta < 0.0;
-  const double lo = lon_lo - delta, hi = lon_hi + delta;
-  const int b0 = max(band - 1, 0), b1 = min(band + 1, g.nb - 1);
-  for (int b = b0; b <= b1; ++b) {
-    const int ncb = g.ncols[b];
+  AgPointWindow w;
+  w.b0 = max(band - 1, 0);
+  w.b1 = min(band + 1, g.nb - 1);
+  w.lo = lon_lo - delta;
+  w.hi = lon_hi + delta;
+  w.full = delta < 0.0 || w.hi - w.lo >= AG_TWO_PI;
+  for (int b = w.b0; b <= w.b1; ++b) {
+    const int nc = g.ncols[b];
     const int base = g.off[b];
-    if (full || ncb == 1 || hi - lo >= AG_TWO_PI) {
-      f(cell_start[base], cell_start[base + ncb]);
-      continue;
-    }
-    const double w = ncb * AG_INV_TWO_PI;
-    const long long ca = static_cast<long long>(floor(lo * w));
-    const long long cb = static_cast<long long>(floor(hi * w));
-    const long long len = cb - ca + 1;
-    if (len >= ncb) {
-      f(cell_start[base], cell_start[base + ncb]);
-      continue;
-    }
-    int cam = static_cast<int>(ca % ncb);
-    if (cam < 0) cam += ncb;
-    if (cam + len <= ncb) {
-      f(cell_start[base + cam], cell_start[base + cam + static_cast<int>(len)]);
-    } else {
-      f(cell_start[base + cam], cell_start[base + ncb]);
-      f(cell_start[base], cell_start[base + cam + static_cast<int>(len) - ncb]);
-    }
+    int c_first, c_last;
+    ag_window_cells(w, nc, false, &c_first, &c_last);
+    f(cell_start[base + c_first], cell_start[base + c_last]);
+    ag_window_cells(w, nc, true, &c_first, &c_last);
+    if (c_last > c_first) f(cell_start[base + c_first], cell_start[base + c_last]);
   }
 }
 
@@ -493,38 +481,69 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
       const double wlon = AG_TWO_PI / a.tgrid.ncols[band];
       lon_lo = col_first * wlon;
       lon_hi = (col_last + 1) * wlon;
-      int n = 0;
-      auto keep = [&](int first, int last) {
-        if (first < last && n < AG_WIN_RANGES) {
-          w->d[1 + 2 * n] = first - total;
-          w->d[2 + 2 * n] = total + (last - first);
-        }
-        if (first < last) {
-          ++n;
-          total += last - first;
-        }
-      };
+      // the window of the range of targets: for targets from a kept binning -- whose bands belong to another grid --
+      // every source cell within the guaranteed radius of the box the range lies in (its band's latitudes, the
+      // longitudes of its cells); otherwise the three bands around the targets' own, with the half-width of the table
+      AgPointWindow pw;
       if (a.foreign_targets) {
-        // the targets' band belongs to another grid: every source cell within the guaranteed radius of the box
-        // the range of targets lies in (its band's latitudes, the longitudes of its cells)
         const double lat_hi = AG_HALF_PI - band * a.tgrid.dlat, lat_lo = lat_hi - a.tgrid.dlat;
-        ag_for_each_range(a.sgrid, a.sstart, lat_lo, lat_hi, lon_lo, lon_hi, a.rg, keep);
-        if (n > AG_WIN_RANGES) {
+        pw = ag_box_window(a.sgrid, lat_lo, lat_hi, lon_lo, lon_hi, a.rg);
+      } else {
+        const double delta = a.sgrid.win[band];
+        pw.b0 = max(band - 1, 0);
+        pw.b1 = min(band + 1, a.sgrid.nb - 1);
+        pw.lo = lon_lo - delta;
+        pw.hi = lon_hi + delta;
+        pw.full = delta < 0.0 || pw.hi - pw.lo >= AG_TWO_PI;
+      }
+      // the table entries of all bands are fetched together, then the cell starts of all runs: two waits for
+      // memory per descriptor instead of two per band
+      constexpr int BANDS = 5;
+      const int nbands = pw.b1 - pw.b0 + 1;
+      int n = 0;
+      if (nbands <= BANDS) {
+        int nc[BANDS], base[BANDS];
+#pragma unroll
+        for (int i = 0; i < BANDS; ++i) {
+          const int b = min(pw.b0 + i, pw.b1);
+          nc[i] = a.sgrid.ncols[b];
+          base[i] = a.sgrid.off[b];
+        }
+        int first[2 * BANDS], last[2 * BANDS];
+#pragma unroll
+        for (int j = 0; j < 2 * BANDS; ++j) {
+          int c_first = 0, c_last = 0;
+          if ((j >> 1) < nbands) ag_window_cells(pw, nc[j >> 1], (j & 1) != 0, &c_first, &c_last);
+          const bool some = c_last > c_first;
+          first[j] = a.sstart[base[j >> 1] + (some ? c_first : 0)];
+          last[j] = a.sstart[base[j >> 1] + (some ? c_last : 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * BANDS; ++j) {
+          if (first[j] < last[j]) {
+            if (n < AG_WIN_RANGES) {
+              w->d[1 + 2 * n] = first[j] - total;
+              w->d[2 + 2 * n] = total + (last[j] - first[j]);
+            }
+            ++n;
+            total += last[j] - first[j];
+          }
+        }
+      }
+      if (nbands > BANDS || n > AG_WIN_RANGES) {
+        if (a.foreign_targets) {
           // more runs than a descriptor holds: one run over all covered bands (their cells are contiguous
           // in the binned array) -- a superset of the window
-          const double pad = 1.0e-7 + 1.0e-6 * a.rg;
-          const int b0 = ag_band_of(a.sgrid, lat_hi + a.rg + pad), b1 = ag_band_of(a.sgrid, lat_lo - a.rg - pad);
-          const int first = a.sstart[a.sgrid.off[b0]], last = a.sstart[a.sgrid.off[b1 + 1]];
+          const int first = a.sstart[a.sgrid.off[pw.b0]], last = a.sstart[a.sgrid.off[pw.b1 + 1]];
           w->d[1] = first;
           w->d[2] = last - first;
           n = last > first ? 1 : 0;
           total = n ? last - first : 0;
+        } else {
+          n = -1;
         }
-        nruns = n;
-      } else {
-        ag_cell_window(a.sgrid, a.sstart, band, lon_lo, lon_hi, keep);
-        nruns = n <= AG_WIN_RANGES ? n : -1;
       }
+      nruns = n;
     } else {
       t0 = t1 = 0;
     }
@@ -1467,29 +1486,43 @@ __global__ __launch_bounds__(256) void ag_radius_window_kernel(AgRadiusArgs a) {
     // the descriptor is written in place: only the runs that hold sources are kept (a band's second run
     // is empty unless the longitude window wraps), so the search's run look-up is as short as the window
     AgRadiusDesc* d = a.desc + t;
-    int run = 0, nruns = 1, kept = 0;
-    bool merged = false;
-    for (int j = 0; j < nruns; ++j) {
-      int first, last;
-      nruns = ag_lane_range(a.grid, a.sstart, tlat, tlonw, a.radius, j, &first, &last);
-      if (nruns > AG_RADIUS_RUNS) {
-        merged = true;
-        break;
+    int run = 0, kept = 0;
+    const AgPointWindow w = ag_point_window(a.grid, tlat, tlonw, a.radius);
+    const int nbands = w.b1 - w.b0 + 1;
+    if (2 * nbands <= AG_RADIUS_RUNS) {
+      // the table entries of all bands are fetched together, then the cell starts of all runs: two waits for
+      // memory per target instead of two per run
+      constexpr int BANDS = AG_RADIUS_RUNS / 2;
+      int nc[BANDS], base[BANDS];
+#pragma unroll
+      for (int i = 0; i < BANDS; ++i) {
+        const int b = min(w.b0 + i, w.b1);
+        nc[i] = a.grid.ncols[b];
+        base[i] = a.grid.off[b];
       }
-      if (last > first) {
-        run += last - first;
-        d->first[kept] = first;
-        d->incl[kept] = run;
-        ++kept;
+      int first[AG_RADIUS_RUNS], last[AG_RADIUS_RUNS];
+#pragma unroll
+      for (int j = 0; j < AG_RADIUS_RUNS; ++j) {
+        int c_first = 0, c_last = 0;
+        if ((j >> 1) < nbands) ag_window_cells(w, nc[j >> 1], (j & 1) != 0, &c_first, &c_last);
+        const bool some = c_last > c_first;
+        first[j] = a.sstart[base[j >> 1] + (some ? c_first : 0)];
+        last[j] = a.sstart[base[j >> 1] + (some ? c_last : 0)];
       }
-    }
-    if (merged) {
+#pragma unroll
+      for (int j = 0; j < AG_RADIUS_RUNS; ++j) {
+        if (last[j] > first[j]) {
+          run += last[j] - first[j];
+          d->first[kept] = first[j];
+          d->incl[kept] = run;
+          ++kept;
+        }
+      }
+    } else {
       // more runs than the descriptor holds: one run over all covered bands (their cells are
       // contiguous in the binned array) -- a superset of the window
-      const double pad = 1.0e-7 + 1.0e-6 * a.radius;
-      const int b0 = ag_band_of(a.grid, tlat + a.radius + pad), b1 = ag_band_of(a.grid, tlat - a.radius - pad);
-      const int first = a.sstart[a.grid.off[b0]];
-      run = a.sstart[a.grid.off[b1 + 1]] - first;
+      const int first = a.sstart[a.grid.off[w.b0]];
+      run = a.sstart[a.grid.off[w.b1 + 1]] - first;
       d->first[0] = first;
       d->incl[0] = run;
       kept = 1;

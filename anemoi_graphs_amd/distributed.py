@@ -194,8 +194,10 @@ class ShardedGraphBuilder:
     def __init__(self, data_x: torch.Tensor, resolution: int, cutoff_factor: float = 0.6,
                  num_nearest_neighbours: int = 3, x_hops: int = 1, rank: int = 0, world_size: int = 1, dist=None,
                  backend=None, attributes: bool = True, edge_length_norm: str | None = "unit-max",
-                 edge_direction_norm: str | None = None, exchange_halo: bool = False):
+                 edge_direction_norm: str | None = None, exchange_halo: bool = False, overlap_processor: bool = True):
         self.backend = _hip_ops if backend is None else backend
+        self.overlap_processor = overlap_processor
+        self._side = {}
         self.resolution = resolution
         self.cutoff_factor = cutoff_factor
         self.k = num_nearest_neighbours
@@ -230,6 +232,13 @@ class ShardedGraphBuilder:
         else:
             self.comm = None
 
+    def _side_stream(self, device):
+        """The second stream of a single-GPU build (default priority), made once per device."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
+
     # ---------------------------------------------------------------------------------- single GPU
     def _build_single(self) -> HeteroData:
         """The plain plugin sequence the orchestrator runs (create.py:78-90 of the reference)."""
@@ -249,10 +258,38 @@ class ShardedGraphBuilder:
             "edge_length": {"_target_": "anemoi.graphs.edges.attributes.EdgeLength", "norm": self.len_norm},
             "edge_dirs": {"_target_": "anemoi.graphs.edges.attributes.EdgeDirection", "norm": self.dir_norm},
         }
-        for b in builders:  # as the orchestrator does: edges first, then the attributes of the edge set
-            graph = b.update_graph(graph, attrs_config=None)
+        def run(b):  # as the orchestrator does: edges first, then the attributes of the edge set
+            b.update_graph(graph, attrs_config=None)
             if self.attributes:
-                graph = b.register_attributes(graph, attrs)
+                b.register_attributes(graph, attrs)
+
+        x = graph["hidden"].x
+        if not (self.overlap_processor and x.is_cuda):
+            for b in builders:
+                run(b)
+            return graph
+        # Two streams.  The processor edges need the hidden mesh and nothing else, and their kernels are many and
+        # small (they wait for memory, not for compute units): they are queued on a second stream, behind the mesh,
+        # and run beside the reference distance of the first.  The decoder search needs the binned data nodes -- which
+        # the encoder makes -- and no answer from the device: queued on the second stream once the binning is, it
+        # fills the GPU while the host waits for the size of the encoder's edge list.  The edge sets are registered
+        # first, so that the graph lists them in the order a sequential build does.
+        from .edges.builder import kept_binning
+
+        encoder, processor, decoder = builders
+        for b in builders:
+            graph[(b.source_name, "to", b.target_name)]
+        main = torch.cuda.current_stream(x.device)
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            run(processor)
+        radius = encoder.get_cutoff_radius(graph)  # (kept with the hidden nodes: the encoder does not compute it again)
+        kept_binning(graph["data"], _hip_ops.radius_cell(self.n_data, radius))
+        with torch.cuda.stream(side):
+            run(decoder)
+        run(encoder)
+        main.wait_stream(side)
         return graph
 
     # ---------------------------------------------------------------------------------- sharded

@@ -180,7 +180,15 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
 
         target_nodes = graph[self.target_name]
         mask = target_nodes[mask_attr] if mask_attr is not None else None
+        # the value stays with the node set (a private attribute, removed when the graph is finished) for the other
+        # cut-off builders of the graph that have these targets
+        key = ops.tensor_key(torch.as_tensor(target_nodes.x))
+        kept = target_nodes["_reference_distance"] if "_reference_distance" in target_nodes else None
+        if mask is None and isinstance(kept, tuple) and kept[0] == key:
+            return kept[1] * self.cutoff_factor
         target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask)
+        if mask is None:
+            target_nodes["_reference_distance"] = (key, target_grid_reference_distance)
         return target_grid_reference_distance * self.cutoff_factor
 
     def prepare_node_data(self, graph: HeteroData) -> tuple[NodeStorage, NodeStorage]:

@@ -102,10 +102,20 @@ class Binning:
 
     def __init__(self, x: torch.Tensor, buffer: torch.Tensor, cell: float, key) -> None:
         self.x, self.buffer, self.cell, self.key = x, buffer, float(cell), key
+        # the stream the binning was built on, and the point of it at which the buffer is complete
+        self.stream = torch.cuda.current_stream(buffer.device)
+        self.ready = torch.cuda.Event()
+        self.ready.record(self.stream)
 
     @property
     def n(self) -> int:
         return int(self.x.shape[0])
+
+    def wait(self) -> None:
+        """Make the current stream wait for the binning (nothing to do on the stream that built it)."""
+        current = torch.cuda.current_stream(self.buffer.device)
+        if current != self.stream:
+            current.wait_event(self.ready)
 
 
 def tensor_key(t: torch.Tensor):
@@ -151,6 +161,7 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
         dist = torch.empty((nt, k), dtype=torch.float64, device=dev) if return_dist else None
         stats = torch.zeros(4, dtype=torch.int64, device=dev)
         if tgt_binning is not None and max_dist is None and nt > 0:
+            tgt_binning.wait()
             ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k), dev)
             _lib.check(
                 lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k, _ptr(out),
@@ -193,6 +204,7 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning
     with _on(dev):
         edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=dev)
         if tgt_binning is not None and nt > 0:
+            tgt_binning.wait()
             ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k), dev)
             _lib.check(
                 lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k,
@@ -256,6 +268,7 @@ def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, src_binnin
                 "ag_radius_count",
             )
         else:
+            src_binning.wait()
             ws = _workspace(lib.ag_radius_binned_workspace_bytes(ns, nt), dev)
             _lib.check(
                 lib.ag_radius_count_binned(_ptr(src), ns, _ptr(src_binning.buffer), src_binning.cell, _ptr(tgt), nt, radius,
