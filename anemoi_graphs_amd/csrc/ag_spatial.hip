@@ -1436,7 +1436,10 @@ extern "C" int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out
 // ---------------------------------------------------------------------------------------------
 #define AG_ROW_LDS 1024  // row entries a wave can sort in LDS
 #define AG_STASH_MAX 256  // longest row the count pass keeps for the fill pass
-#define AG_STASH_BUDGET (int64_t(1) << 28)  // entries of the stash over all targets (1 GiB)
+// Entries of the stash over all targets: 8 GiB of a 288 GB card.  (With 1 GiB the ten million targets of an
+// icosphere of level 10 kept rows of 16 entries at most, and nearly every row of a 1 km encoder -- 66 sources on
+// average -- went the way of the long rows: searched twice and sorted by a segmented radix sort, 15 ms of 92.)
+#define AG_STASH_BUDGET (int64_t(1) << 31)
 #define AG_RADIUS_RUNS 8  // runs of binned sources in a target's window (3 bands x 2 + spare)
 
 // What the search needs to know about a target, computed once per target by one thread

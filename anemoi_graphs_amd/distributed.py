@@ -26,6 +26,8 @@ nor occupy the stream), and the all-gathers of the edge lists into their final p
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 from . import ops as _hip_ops
@@ -194,9 +196,13 @@ class ShardedGraphBuilder:
     def __init__(self, data_x: torch.Tensor, resolution: int, cutoff_factor: float = 0.6,
                  num_nearest_neighbours: int = 3, x_hops: int = 1, rank: int = 0, world_size: int = 1, dist=None,
                  backend=None, attributes: bool = True, edge_length_norm: str | None = "unit-max",
-                 edge_direction_norm: str | None = None, exchange_halo: bool = False, overlap_processor: bool = True):
+                 edge_direction_norm: str | None = None, exchange_halo: bool = False, overlap_processor: bool | None = None):
         self.backend = _hip_ops if backend is None else backend
-        self.overlap_processor = overlap_processor
+        # Two streams for a single-GPU build (see _build_single).  Handing work from one stream to the other costs
+        # the device about 30 us each time, 0.13 ms per build: worth it when the searches run for longer than that
+        # (measured: O1280 -> r7 1.20 -> 1.04 ms per build, ERA5 0.25 deg -> r6 0.73 -> 0.89 ms), hence by default
+        # only for data grids of a few million nodes.
+        self.overlap_processor = int(data_x.shape[0]) >= 2_500_000 if overlap_processor is None else overlap_processor
         self._side = {}
         self.resolution = resolution
         self.cutoff_factor = cutoff_factor
@@ -248,6 +254,23 @@ class ShardedGraphBuilder:
         graph = HeteroData()
         graph["data"].x = self.data_full
         graph["data"].node_type = "LatLonNodes"
+        overlap = self.overlap_processor and torch.as_tensor(self.data_full).is_cuda and self.backend is _hip_ops
+        if overlap:
+            # The binning of the data nodes that the encoder and the decoder share needs the cut-off radius only for
+            # the size of its cells, and that within a factor: it is started now, on the second stream, beside the
+            # generation of the mesh, with the radius a quasi-uniform mesh of this many nodes will turn out to have
+            # (reference distance = 1.18 x the mean node spacing for icospheres of level 5 and above, less for coarser
+            # ones).  The encoder takes the binning if its cells are within its accepted range of the ones it would
+            # choose for the radius it then computes, and bins again otherwise.
+            from .edges.builder import kept_binning
+
+            dev = self.data_full.device
+            main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+            n_hidden = 10 * 4 ** self.resolution + 2
+            guess = self.cutoff_factor * 1.185 * math.sqrt(4.0 * math.pi / n_hidden)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                kept_binning(graph["data"], _hip_ops.radius_cell(self.n_data, guess))
         graph = TriNodes(self.resolution, "hidden").update_graph(graph, {})
         builders = [
             CutOffEdges("data", "hidden", self.cutoff_factor),
@@ -264,7 +287,7 @@ class ShardedGraphBuilder:
                 b.register_attributes(graph, attrs)
 
         x = graph["hidden"].x
-        if not (self.overlap_processor and x.is_cuda):
+        if not (overlap and x.is_cuda):
             for b in builders:
                 run(b)
             return graph
@@ -274,13 +297,9 @@ class ShardedGraphBuilder:
         # the encoder makes -- and no answer from the device: queued on the second stream once the binning is, it
         # fills the GPU while the host waits for the size of the encoder's edge list.  The edge sets are registered
         # first, so that the graph lists them in the order a sequential build does.
-        from .edges.builder import kept_binning
-
         encoder, processor, decoder = builders
         for b in builders:
             graph[(b.source_name, "to", b.target_name)]
-        main = torch.cuda.current_stream(x.device)
-        side = self._side_stream(x.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             run(processor)

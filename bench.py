@@ -247,7 +247,7 @@ def main() -> None:
         builder = ShardedGraphBuilder(
             data, resolution, cutoff_factor=CUTOFF_FACTOR, num_nearest_neighbours=KNN_K, x_hops=X_HOPS,
             rank=rank, world_size=world, dist=dist, exchange_halo=args.exchange_halo,
-            overlap_processor=not args.no_overlap,
+            overlap_processor=False if args.no_overlap else None,
         )
         workload_name = f"{grid_name.upper()} ({n_data} nodes)"
 
