@@ -378,8 +378,10 @@ class ShardedGraphBuilder:
         targets = hidden[h_lo:h_hi].contiguous()
         mark("reference_distance_and_halo")
         enc = be.radius_edges(sources, targets, radius)
-        enc[0] += g_lo
-        enc[1] += h_lo
+        if g_lo:
+            enc[0] += g_lo
+        if h_lo:
+            enc[1] += h_lo
         mark("encoder_search")
         enc_counts_ready = comm.all_gather_sizes_async([enc.shape[1]], dev)  # read once the processor is queued
 
@@ -605,19 +607,24 @@ class BandGraphBuilder:
 
         # ---- decoder: hidden sources, my band as targets
         if self.decoder:
-            dec = torch.empty((2, nd * self.k), dtype=torch.int32, device=dev)
-            own_cell = (40.0 / max(nh, 1)) ** 0.5 if self.k == 3 else ((2.0 * (self.k + 1) + 2.0) * 4.0 / max(nh, 1)) ** 0.5
-            if kept is not None and sources.shape[0] <= nd + nd // 8 and kept.cell <= 1.5 * own_cell:
-                ids = be.knn(hidden, None, self.k, tgt_binning=kept)
-                dec[0] = ids[before:before + nd].reshape(-1)
+            own_cell = ((2.0 * (self.k + 1) + 2.0) * 4.0 / max(nh, 1)) ** 0.5
+            binned = kept is not None and sources.shape[0] <= nd + nd // 8 and kept.cell <= 1.5 * own_cell
+            if binned and sources.shape[0] == nd:  # no halo rows: the search writes the edge list itself
+                dec = be.knn_edges(hidden, None, self.k, tgt_binning=kept)
             else:
-                dec[0] = be.knn(hidden, self.data_band, self.k).reshape(-1)
-            be.row_ids(nd, self.k, dev, out=dec[1])
+                dec = torch.empty((2, nd * self.k), dtype=torch.int32, device=dev)
+                if binned:
+                    ids = be.knn(hidden, None, self.k, tgt_binning=kept)
+                    dec[0] = ids[before:before + nd].reshape(-1)
+                else:
+                    dec[0] = be.knn(hidden, self.data_band, self.k).reshape(-1)
+                be.row_ids(nd, self.k, dev, out=dec[1])
             mark("decoder_search")
             if self.attributes:
                 self._edge_attributes(graph[dec_name], hidden, self.data_band, dec)
                 mark("decoder_attributes")
-            dec[1] += self.first_id
+            if self.first_id:
+                dec[1] += self.first_id
             graph[dec_name].edge_index = dec
             graph[dec_name].edge_type = "KNNEdges"
         else:
@@ -628,11 +635,13 @@ class BandGraphBuilder:
         enc = (be.radius_edges(None, targets, radius, src_binning=kept) if kept is not None
                else be.radius_edges(sources, targets, radius))
         mark("encoder_search")
-        enc[1] += h_lo
+        if h_lo:  # (a pass over the list each: not made for a band that starts at the first node)
+            enc[1] += h_lo
         if self.attributes:
             self._edge_attributes(graph[enc_name], sources, hidden, enc)
             mark("encoder_attributes")
-        enc[0] += g_lo
+        if g_lo:
+            enc[0] += g_lo
         graph[enc_name].edge_index = enc
         graph[enc_name].edge_type = "CutOffEdges"
         graph[enc_name]["_radius"] = radius
