@@ -355,17 +355,25 @@ def main() -> None:
             roofline["unique_bytes_per_launch"] = strict
             roofline["frac_unique_bytes"] = round(strict / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if isolated_ms and name in isolated_ms and isolated_ms[name][1] > 0:
+            # Two streams: the roofline figures describe the kernel, so they are taken from its launches alone (the
+            # same builds on one stream, run after the timed region); what the same launches took in the timed
+            # region, beside the kernels of the other stream, is stated next to them.
             iso_launches, iso_total = isolated_ms[name]
             iso_avg = iso_total / max(iso_launches, 1)
-            roofline["concurrent_streams"] = 2
-            roofline["note"] = ("achieved / frac: launches of the timed region, where the kernel shares the GPU with the "
-                                "kernels of the second stream; alone: the same launches in builds on one stream, run "
-                                "after the timed region")
-            roofline["alone"] = {
+            roofline["timed_region"] = {
+                "concurrent_streams": 2, "avg_launch_ms": roofline["avg_launch_ms"], "launches": launches,
+                "achieved": roofline["achieved"], "frac": roofline["frac"],
+            }
+            roofline["measured"] = ("the kernel's launches alone: the same builds on one stream (--no-overlap), run after "
+                                    "the timed region; timed_region: the launches of the timed region, where the "
+                                    "kernel shares the GPU with the kernels of the second stream")
+            roofline.update({
                 "avg_launch_ms": round(iso_avg, 4), "launches": iso_launches,
                 "achieved": round(nbytes / (iso_avg * 1e-3) / 1e9, 2),
                 "frac": round(nbytes / (iso_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            }
+            })
+            if strict is not None:
+                roofline["frac_unique_bytes"] = round(strict / (iso_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
 
     if stretched:
         parallelism = "single GPU" if world == 1 else f"latitude bands x{world}, band-local input and output, halo rows only"
