@@ -27,16 +27,24 @@ _ALIASES = {
 }
 
 
+_RESOLVED: dict[str, object] = {}  # (the import machinery costs tens of microseconds per look-up, a build makes a dozen)
+
+
 def resolve(target: str):
-    target = _ALIASES.get(target, target)
-    module, _, name = target.rpartition(".")
+    found = _RESOLVED.get(target)
+    if found is not None:
+        return found
+    aliased = _ALIASES.get(target, target)
+    module, _, name = aliased.rpartition(".")
     try:
-        return getattr(importlib.import_module(module), name)
+        found = getattr(importlib.import_module(module), name)
     except (ImportError, AttributeError) as e:
         raise ImportError(
-            f"cannot instantiate {target!r}: only the graph-construction hot path is provided by this package "
+            f"cannot instantiate {aliased!r}: only the graph-construction hot path is provided by this package "
             f"({', '.join(sorted(_ALIASES))})"
         ) from e
+    _RESOLVED[target] = found
+    return found
 
 
 def instantiate(config, **kwargs):

@@ -50,7 +50,13 @@ def _ptr(t: torch.Tensor | None):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (the handle without a Stream object around it)
+
+
 def _stream(device: torch.device):
+    if _RAW_STREAM is not None:
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        return ctypes.c_void_p(_RAW_STREAM(index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
