@@ -146,3 +146,58 @@ def test_attributes_on_samples(built):
         print(f"{name}: {int((~ok).sum())} zero-length edges in the sample")
         raw_dir = rp.edge_directions(sx, tx, es).astype(np.float32)  # the builder's direction norm is None
         _close(dirs[sample][ok], raw_dir[ok], f"{name} edge_dirs", small=DIR_SMALL)
+
+
+@pytest.mark.parametrize("grid,resolution", [("o1280", 7), ("era5", 6)])
+def test_two_streams_build_the_same_graph(grid, resolution):
+    """A single-GPU build on two streams (processor and decoder beside the encoder, the data nodes binned before the
+    mesh exists) and the same build on one stream: every tensor of the two graphs is identical, bit for bit, and the
+    edge sets are listed in the same order.  Three builds on two streams in a row, so that a result that depended on
+    the timing of the streams would show."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    device = torch.device("cuda", 0)
+    data = torch.from_numpy(grids.named(grid)).to(device)
+    graphs = []
+    for overlap in (False, True, True, True):
+        builder = ShardedGraphBuilder(data, resolution, cutoff_factor=0.6, num_nearest_neighbours=3, x_hops=1,
+                                      overlap_processor=overlap)
+        with settings.resident(True):
+            graphs.append(builder.build())
+        torch.cuda.synchronize()
+    want = graphs[0]
+    for got in graphs[1:]:
+        assert list(got.edge_types) == list(want.edge_types)
+        assert list(got.node_types) == list(want.node_types)
+        for name in want.node_types:
+            assert torch.equal(got[name].x, want[name].x), name
+        for name in want.edge_types:
+            assert torch.equal(got[name].edge_index, want[name].edge_index), name
+            for attr in ("edge_length", "edge_dirs"):
+                a, b = got[name][attr], want[name][attr]
+                assert a.dtype == b.dtype and torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, attr)
+
+
+def test_a_binning_made_on_another_stream_is_waited_for():
+    """A kept binning records the stream it was built on; a search queued on another stream right behind it -- no
+    synchronisation in between -- gives the edges of a search on one stream."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from anemoi_graphs_amd import ops
+
+    device = torch.device("cuda", 0)
+    data = torch.from_numpy(grids.named("era5")).to(device)
+    hidden = torch.from_numpy(rp.tri_nodes(5)[0].astype(np.float32)).to(device)
+    radius = 0.03
+    want = ops.radius_edges(data, hidden, radius)
+    want_knn = ops.knn_edges(hidden, data, 3)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=device)
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            kept = ops.bin_points(data, ops.radius_cell(data.shape[0], radius))
+        got = ops.radius_edges(None, hidden, radius, src_binning=kept)  # current stream: waits for `side`
+        got_knn = ops.knn_edges(hidden, None, 3, tgt_binning=kept)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(got_knn, want_knn)
