@@ -40,6 +40,7 @@ SIGNATURES = {
         c_int, [_P, c_int64, _P, c_double, _P, c_int64, c_double, _P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
     "ag_knn_binned_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "ag_knn_binned": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_knn_edges": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "ag_icosphere_sizes": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "ag_icosphere_workspace_bytes": (c_size_t, [c_int]),
     "ag_icosphere": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

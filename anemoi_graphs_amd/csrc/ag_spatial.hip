@@ -279,6 +279,7 @@ struct AgKnnArgs {
   double rg;                 // angular radius a tile is guaranteed to cover
   float rg_chord2;           // conservative float32 chord^2 of rg
   int32_t* out_src;          // [nt*k]
+  int32_t* out_tgt;          // [nt*k] or null: the target of every entry of out_src (the second row of an edge list)
   double* out_dist;          // [nt*k] or null
   int* cand_n;               // [cand_slots] per re-rank queue slot: number of candidates to re-rank in float64
   int* cand_t;               // [cand_slots] per re-rank queue slot: the binned target
@@ -309,6 +310,7 @@ struct AgKnnArgs {
 // hundred lane writes per wave before the first useful instruction); the grids are only needed by a window with
 // more runs than its descriptor holds, which reads them from `full`, the copy the window kernel left in device memory.
 struct AgKnnHot {
+  int32_t* out_tgt;
   int* rq_count;
   int64_t cand_slots;
   int rq, rq_cap;
@@ -809,6 +811,12 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
 #pragma unroll
       for (int j = 0; j < CAP; ++j)
         if (j < k) o[j] = bi[j];
+      if (a.out_tgt != nullptr) {
+        int32_t* ot = a.out_tgt + static_cast<int64_t>(tid) * k;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j)
+          if (j < k) ot[j] = tid;
+      }
     }
     if (RESOLVE) {
       // targets whose list has to be re-ranked in float64 are appended to a queue (one atomic per
@@ -908,6 +916,12 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
 #pragma unroll
       for (int j = 0; j < CAP; ++j)
         if (j < k) o[j] = bi[j];
+      if (a.out_tgt != nullptr) {
+        int32_t* ot = a.out_tgt + static_cast<int64_t>(tid) * k;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j)
+          if (j < k) ot[j] = tid;
+      }
     }
   }
   if (a.self_query) {
@@ -1018,12 +1032,16 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
             atomicMax(a.max_bits, static_cast<unsigned long long>(__double_as_longlong(m.r)));
         } else if (lane == 0) {
           a.out_src[static_cast<int64_t>(tid) * k + j] = m.id;
+          if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
         }
       }
       if (covered || whole) break;
       if (last) {
         if (lane == 0 && !a.self_query)
-          for (int j = found; j < k; ++j) a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
+          for (int j = found; j < k; ++j) {
+            a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
+            if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
+          }
         break;
       }
       R *= 2.0;
@@ -1180,6 +1198,7 @@ static void ag_launch_stage1_k(const AgKnnArgs& a, hipStream_t stream) {
   h.tids = a.tids;
   h.tgt = a.tgt;
   h.out_src = a.out_src;
+  h.out_tgt = a.out_tgt;
   h.cand_n = a.cand_n;
   h.cand_t = a.cand_t;
   h.cand_ids = a.cand_ids;
@@ -1221,7 +1240,7 @@ static void ag_launch_stage1(const AgKnnArgs& a, hipStream_t stream) {
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
                       int32_t* d_out_src, double* d_out_dist, double* d_out_max, int64_t* d_stats, void* d_ws,
                       size_t ws_bytes, hipStream_t stream, double max_dist = 0.0,
-                      const AgKeptBinning& kept_tgt = AgKeptBinning()) {
+                      const AgKeptBinning& kept_tgt = AgKeptBinning(), int32_t* d_out_tgt = nullptr) {
   AgCarver sizing(nullptr);
   ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr, kept_tgt);
   if (ws_bytes < sizing.total()) return ag_fail(AG_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sizing.total());
@@ -1251,6 +1270,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     a.rg_chord2 = static_cast<float>(4.0 * s * s * (1.0 - 1.0e-4));
   }
   a.out_src = d_out_src;
+  a.out_tgt = d_out_tgt;
   a.out_dist = d_out_dist;
   a.cand_n = w.cand_n;
   a.cand_t = w.cand_t;
@@ -1354,6 +1374,27 @@ extern "C" int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt,
   kept.cell = tgt_cell;
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
                     static_cast<hipStream_t>(stream), 0.0, kept);
+}
+
+// The k-NN graph as an edge list: what ag_knn (ag_knn_binned with a binning of the targets) finds, with the target of
+// every entry written beside it by the same kernels
+extern "C" int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
+                            double tgt_cell, int k, int32_t* d_edge_src, int32_t* d_edge_tgt, int64_t* d_stats, void* d_ws,
+                            size_t ws_bytes, void* stream) {
+  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_edges: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(ns >= k, "ag_knn_edges: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
+  AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn_edges: node counts must fit int32");
+  AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn_edges: output too large");
+  if (nt == 0) return AG_OK;
+  AG_REQUIRE(d_src && d_tgt && d_edge_src && d_edge_tgt && d_ws, "ag_knn_edges: null pointer");
+  AgKeptBinning kept;
+  if (d_tgt_binning != nullptr) {
+    AG_REQUIRE(tgt_cell > 0.0, "ag_knn_edges: the cell size of the binning must be the one it was built with");
+    kept.buffer = d_tgt_binning;
+    kept.cell = tgt_cell;
+  }
+  return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_edge_src, nullptr, nullptr, d_stats, d_ws, ws_bytes,
+                    static_cast<hipStream_t>(stream), 0.0, kept, d_edge_tgt);
 }
 
 extern "C" int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double max_dist,

@@ -209,22 +209,17 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ns}")
     with _on(dev):
         edge_index = torch.empty((2, nt * k), dtype=torch.int32, device=dev)
-        if tgt_binning is not None and nt > 0:
+        binned = tgt_binning is not None and nt > 0
+        if binned:
             tgt_binning.wait()
-            ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k), dev)
-            _lib.check(
-                lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k,
-                                  _ptr(edge_index[0]), None, None, _ptr(ws), ws.numel(), _stream(dev)),
-                "ag_knn_binned",
-            )
-        else:
-            ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
-            _lib.check(
-                lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(edge_index[0]), None, None, _ptr(ws), ws.numel(),
-                           _stream(dev)),
-                "ag_knn",
-            )
-        _lib.check(lib.ag_fill_row_ids(_ptr(edge_index[1]), nt, k, _stream(dev)), "ag_fill_row_ids")
+        ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k) if binned else lib.ag_knn_workspace_bytes(ns, nt, k), dev)
+        # (both rows come from the search kernels: the target row needs no pass of its own)
+        _lib.check(
+            lib.ag_knn_edges(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer) if binned else None,
+                             tgt_binning.cell if binned else 0.0, k, _ptr(edge_index[0]), _ptr(edge_index[1]), None,
+                             _ptr(ws), ws.numel(), _stream(dev)),
+            "ag_knn_edges",
+        )
     return edge_index
 
 

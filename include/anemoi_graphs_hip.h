@@ -139,6 +139,14 @@ int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt
                   double tgt_cell, int k, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
                   size_t ws_bytes, void* stream);
 
+/* The k-NN graph as an edge list [2, nt*k] (edges/builder.py:259-265: the COO form of kneighbors_graph): d_edge_src =
+ * what ag_knn writes, d_edge_tgt = the target of every entry (0,0,0,1,1,1,... for k = 3), written by the same
+ * kernels instead of a pass of its own (ag_fill_row_ids).  d_tgt_binning: a binning of the targets as for
+ * ag_knn_binned (workspace ag_knn_binned_workspace_bytes), or NULL (workspace ag_knn_workspace_bytes). */
+int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
+                 double tgt_cell, int k, int32_t* d_edge_src, int32_t* d_edge_tgt, int64_t* d_stats, void* d_ws,
+                 size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Icosphere nodes.
  * Replaces trimesh.creation.icosphere(subdivisions=R, radius=1.0) + cartesian_to_latlon_rad +

@@ -249,3 +249,17 @@ def test_builders_share_one_binning_of_the_data_nodes(device):
             graph = KNNEdges("hidden", "data", 3).update_graph(graph)
             graph = GraphCreator({"nodes": {}, "edges": []}).clean(graph)
             assert "_binning" not in graph["data"]
+
+
+def test_knn_edges_entry_point_writes_both_rows(device):
+    """ag_knn_edges = ag_knn + the target of every entry, with or without a binning of the targets."""
+    from anemoi_graphs_amd import ops
+
+    src, tgt = grids.fibonacci_sphere(5000), grids.regular(3.0)
+    k = 4
+    s, t = torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device)
+    ids = ops.knn(s, t, k)
+    want = torch.stack([ids.reshape(-1), torch.arange(len(tgt), device=device, dtype=torch.int32).repeat_interleave(k)])
+    assert torch.equal(ops.knn_edges(s, t, k), want)
+    kept = ops.bin_points(t, 0.05)
+    assert torch.equal(ops.knn_edges(s, None, k, tgt_binning=kept), want)
