@@ -92,12 +92,14 @@ def to_host(graph):
     """Move every device tensor of the graph to host memory, in place (a graph file must load without a GPU)."""
     import torch
 
+    from .utils import to_host as tensor_to_host
+
     for name in [*graph.node_types, *graph.edge_types]:
         store = graph[name]
         for key in list(store.keys()):
             value = store[key]
             if isinstance(value, torch.Tensor) and value.is_cuda:
-                store[key] = value.cpu()
+                store[key] = tensor_to_host(value)
     return graph
 
 
