@@ -506,7 +506,7 @@ class BandGraphBuilder:
     def __init__(self, data_band: torch.Tensor, first_id: int, n_data: int, resolution: int, cutoff_factor: float = 0.6,
                  num_nearest_neighbours: int = 3, x_hops: int = 1, rank: int = 0, world_size: int = 1, dist=None,
                  backend=None, attributes: bool = True, edge_length_norm: str | None = "unit-max",
-                 decoder: bool = True, processor: bool = True):
+                 decoder: bool = True, processor: bool = True, overlap: bool = True):
         if edge_length_norm not in (None, "unit-max", "unit-range"):
             raise ValueError("a band build normalises edge lengths by their range only (None, unit-max, unit-range)")
         self.backend = _hip_ops if backend is None else backend
@@ -516,6 +516,8 @@ class BandGraphBuilder:
         self.rank, self.world = rank, world_size
         self.attributes, self.len_norm = attributes, edge_length_norm
         self.decoder, self.processor = decoder, processor
+        self.overlap = overlap  # second stream for the processor edges (and, on one rank, an early binning of the band)
+        self._side = None
         self.timer = PhaseTimer()
         lat = self.data_band[:, 0]
         if lat.numel() > 1 and bool((lat[1:] > lat[:-1]).any()):
@@ -561,12 +563,43 @@ class BandGraphBuilder:
             store["edge_length"] = be.normalise_band_(length.reshape(-1, 1), self.len_norm, self.comm)
         store["edge_dirs"] = direction
 
+    def _processor_edges(self, graph, proc_name, hidden, rank_map, level_edges, mark) -> None:
+        be = self.backend
+        proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map, level_edges)
+        graph[proc_name].edge_index = proc
+        graph[proc_name].edge_type = "MultiScaleEdges"
+        mark("processor_search")
+        if self.attributes:
+            length, direction, len_range = (be.edge_attrs(hidden, hidden, proc, len_range=True) if be is _hip_ops
+                                            else (*be.edge_attrs(hidden, hidden, proc), None))
+            extra = {} if len_range is None else {"value_range": len_range}
+            graph[proc_name]["edge_length"] = be.normalise_(length.reshape(-1, 1).contiguous(), self.len_norm, **extra)
+            graph[proc_name]["edge_dirs"] = direction
+            mark("processor_attributes")
+
     def build(self) -> HeteroData:
         be, r, W = self.backend, self.rank, self.world
         dev = self.data_band.device
         mark = self.timer.mark
         mark("start")
         graph = HeteroData()
+        nd = self.data_band.shape[0]
+        # Second stream (not while the phases are being timed: they are phases of one stream).  On one rank the band
+        # is all there is to bin, and the binning needs the cut-off radius only for the size of its cells: it is
+        # started now, beside the generation of the mesh, for the radius a quasi-uniform mesh of this size will have
+        # (see ShardedGraphBuilder._build_single), and taken later if its cells are within the accepted range.
+        two_streams = self.overlap and be is _hip_ops and dev.type == "cuda" and not self.timer.enabled
+        main = side = early = None
+        if two_streams:
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(main)
+            if W == 1 and nd > 0:
+                guess = self.cutoff_factor * 1.185 * math.sqrt(4.0 * math.pi / (10 * 4 ** self.resolution + 2))
+                with torch.cuda.stream(side):
+                    early = be.bin_points(self.data_band, be.radius_cell(nd, guess))
         _xyz, _faces, hidden, _order, rank_map, level_edges = be.icosphere(self.resolution)
         hidden = hidden.to(dev)
         nh = hidden.shape[0]
@@ -579,6 +612,10 @@ class BandGraphBuilder:
         enc_name, proc_name, dec_name = ("data", "to", "hidden"), ("hidden", "to", "hidden"), ("hidden", "to", "data")
         for name in (enc_name, proc_name, dec_name):
             graph[name]
+        if two_streams and self.processor:  # the processor edges need the mesh and nothing else
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._processor_edges(graph, proc_name, hidden, rank_map, level_edges, mark)
 
         # ---- sources of the encoder: my band plus the rows my neighbours send
         radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
@@ -601,8 +638,13 @@ class BandGraphBuilder:
         # itself, the decoder (as its targets: the few halo rows are searched too and dropped)
         kept = None
         if be is _hip_ops and sources.shape[0] > 0:
-            kept = be.bin_points(sources, be.radius_cell(sources.shape[0], radius))
+            cell = be.radius_cell(sources.shape[0], radius)
+            if early is not None and sources is self.data_band and 0.8 * cell <= early.cell <= 2.0 * cell:
+                kept = early
+            else:
+                kept = be.bin_points(sources, cell)
             mark("binning")
+        del early
         before = self.first_id - g_lo  # halo rows in front of my band
 
         # ---- decoder: hidden sources, my band as targets
@@ -648,19 +690,10 @@ class BandGraphBuilder:
         del kept
 
         # ---- processor: replicated
-        if self.processor:
-            proc = be.multiscale_edges(self.resolution, list(range(self.resolution + 1)), self.x_hops, rank_map,
-                                       level_edges)
-            graph[proc_name].edge_index = proc
-            graph[proc_name].edge_type = "MultiScaleEdges"
-            mark("processor_search")
-            if self.attributes:
-                length, direction, len_range = (be.edge_attrs(hidden, hidden, proc, len_range=True) if be is _hip_ops
-                                                else (*be.edge_attrs(hidden, hidden, proc), None))
-                extra = {} if len_range is None else {"value_range": len_range}
-                graph[proc_name]["edge_length"] = be.normalise_(length.reshape(-1, 1).contiguous(), self.len_norm, **extra)
-                graph[proc_name]["edge_dirs"] = direction
-                mark("processor_attributes")
-        else:
+        if not self.processor:
             del graph._stores[proc_name]
+        elif two_streams:
+            main.wait_stream(side)  # (queued on the second stream, behind the mesh)
+        else:
+            self._processor_edges(graph, proc_name, hidden, rank_map, level_edges, mark)
         return graph
