@@ -29,6 +29,9 @@ def device_of(*tensors: torch.Tensor) -> torch.device:
 
 def coords(x, device: torch.device) -> torch.Tensor:
     """float32 contiguous [N,2] copy/view of node coordinates on ``device``."""
+    if (isinstance(x, torch.Tensor) and x.dtype is torch.float32 and x.device == device and x.ndim == 2
+            and x.shape[1] == 2 and x.is_contiguous()):
+        return x  # (already what is wanted: the conversions below cost the host microseconds even when they do nothing)
     t = torch.as_tensor(x)
     if t.ndim != 2 or t.shape[1] != 2:
         raise ValueError(f"coordinates must have shape [N, 2], got {tuple(t.shape)}")
