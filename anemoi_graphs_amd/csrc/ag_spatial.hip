@@ -294,6 +294,7 @@ struct AgKnnArgs {
   int nwin;                  // number of descriptors (an upper bound known to the host; unused ones are empty)
   int by_range;              // 1: a descriptor is `range_len` consecutive binned targets of one band; 0: a target cell
   int range_len;             // 64 for dense target sets; fewer for a set queried against itself (sparse: the window grows with the span)
+  int per_target;            // 1: no descriptors and no binned targets -- every lane of stage 1 takes one target, in the caller's order
   const int* tcell_of;       // cell of every target, by original id
   int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
   int bounded;               // 1: neighbours farther than rmax are not wanted (their entries become -1)
@@ -446,6 +447,7 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   }
   if (blockIdx.x == 0)  // fill of the float64 re-rank queues
     for (int q = threadIdx.x; q < a.rq; q += blockDim.x) a.rq_count[q * AG_KNN_RQ_STRIDE] = 0;
+  if (a.per_target) return;  // (no descriptors, and no target grid to read)
   const int nb = a.tgrid.nb;
   const int* range_off = a.range_off;
   const int used = a.by_range ? range_off[nb] : a.tgrid.off[nb];
@@ -623,6 +625,105 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
   }
 }
 
+// The end of stage 1 for the target of a lane, given the CAP best candidates (float32 chord^2, ascending, with
+// their ids) of the region the lane scanned: `ti` is what the re-ranking finds the target by (its position in the
+// binned targets, or the target itself when they are not binned), `wi` the number of the wave's piece of work (it
+// selects the re-rank queue), `tagged` whether the chord^2 values lost their low mantissa bits to a tag.
+template <int CAP, int K>
+__device__ __forceinline__ void ag_knn_classify(const AgKnnHot a, const bool active, const bool tagged, const int tid,
+                                                const int ti, const int wi, const float (&bd)[CAP], const int (&bi)[CAP]) {
+  const int lane = ag_lane();
+  const int k = K > 0 ? K : a.k;
+  // Let dk be the float32 chord^2 of the k-th entry and ek its error bound.  Every candidate whose
+  // float32 value exceeds thr_hi = dk + 3 ek + 4e-12 is provably farther (in exact arithmetic)
+  // than each of the first k entries [x - err(x) >= dk + ek for x >= thr_hi], so the exact k nearest
+  // are among the entries up to the last one below thr_hi ("cluster end" c1).  The list is
+  //   final      if c1 is the k-th entry itself and the first k gaps exceed their error bounds,
+  //   re-ranked  in float64 by ag_knn_resolve_kernel if c1 lies inside the list,
+  //   queued     for stage 2 if the cluster may run past the list or the k-th entry is not provably
+  //              inside the region the tile covers.
+  constexpr bool RESOLVE = (CAP <= AG_KNN_RESOLVE_CAP);
+  float dk = 3.0e38f;
+  int ik = -1;
+#pragma unroll
+  for (int j = 0; j < CAP; ++j)
+    if (j == k - 1) {
+      dk = bd[j];
+      ik = bi[j];
+    }
+  auto err_of = [&](float c2) { return tagged ? ag_chord2_err_tagged(c2) : ag_chord2_err(c2); };
+  const float ek = err_of(dk);
+  const float thr_hi = dk + 3.0f * ek + 4.0e-12f;
+  const bool have_k = active && (ik >= 0);
+  bool queued = active && !have_k;
+  int c1 = k - 1;
+#pragma unroll
+  for (int j = 0; j < CAP; ++j)
+    if (j >= k && bd[j] <= thr_hi) c1 = j;
+  bool exact = false;
+  if (have_k) {
+    if (c1 == CAP - 1) queued = true;
+    if (dk + ek > a.rg_chord2) queued = true;
+    exact = (c1 != k - 1);
+#pragma unroll
+    for (int j = 0; j + 1 < CAP; ++j)
+      if (j + 1 < k) exact = exact || ((bd[j + 1] - bd[j]) <= (err_of(bd[j + 1]) + err_of(bd[j])));
+    if (a.self_query) exact = true;  // the value of the 2nd smallest rdist is needed anyway
+    if (!RESOLVE && exact) queued = true;
+  }
+  const bool done = have_k && !queued;
+  if (done && !exact) {
+    int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
+#pragma unroll
+    for (int j = 0; j < CAP; ++j)
+      if (j < k) o[j] = bi[j];
+    if (a.out_tgt != nullptr) {
+      int32_t* ot = a.out_tgt + static_cast<int64_t>(tid) * k;
+#pragma unroll
+      for (int j = 0; j < CAP; ++j)
+        if (j < k) ot[j] = tid;
+    }
+  }
+  if (RESOLVE) {
+    // targets whose list has to be re-ranked in float64 are appended to a queue (one atomic per
+    // wave); the candidate lists are stored by queue slot, coalesced per rank
+    const bool rec = active && done && exact;
+    const unsigned long long m = __ballot(rec);
+    if (a.self_query) {
+      // every target is re-ranked (the value of its 2nd smallest rdist is needed): slot = target
+      if (active) {
+        a.cand_n[ti] = rec ? c1 + 1 : 0;
+        a.cand_t[ti] = ti;
+        if (rec) {
+#pragma unroll
+          for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + ti] = bi[j];
+        }
+      }
+    } else if (m) {
+      int base = 0;
+      const int leader = __ffsll(static_cast<long long>(m)) - 1;
+      const int q = wi & (a.rq - 1);
+      if (lane == leader) base = atomicAdd(a.rq_count + q * AG_KNN_RQ_STRIDE, __popcll(m));
+      base = __shfl(base, leader, 64) + q * a.rq_cap;
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (rec && slot < a.cand_slots) {  // (a queue holds every target that can reach it: the bound only guards the store)
+        a.cand_n[slot] = c1 + 1;
+        a.cand_t[slot] = ti;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + slot] = bi[j];
+      }
+    }
+  }
+  const unsigned long long mq = __ballot(queued);
+  if (mq) {  // stage-2 queue: one atomic per wave
+    int base = 0;
+    const int leader = __ffsll(static_cast<long long>(mq)) - 1;
+    if (lane == leader) base = atomicAdd(a.queue_count, __popcll(mq));
+    base = __shfl(base, leader, 64);
+    if (queued) a.queue[base + __popcll(mq & ((1ull << lane) - 1ull))] = tid;
+  }
+}
+
 // K = the number of neighbours when it is one of the small values instantiated below (the comparisons with it then
 // cost nothing), 0 = read it from the arguments.
 template <int CAP, int K>
@@ -767,96 +868,80 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       }
     }
 
-    // ---- classify -------------------------------------------------------------------------
-    // Let dk be the float32 chord^2 of the k-th entry and ek its error bound.  Every candidate whose
-    // float32 value exceeds thr_hi = dk + 3 ek + 4e-12 is provably farther (in exact arithmetic)
-    // than each of the first k entries [x - err(x) >= dk + ek for x >= thr_hi], so the exact k nearest
-    // are among the entries up to the last one below thr_hi ("cluster end" c1).  The list is
-    //   final      if c1 is the k-th entry itself and the first k gaps exceed their error bounds,
-    //   re-ranked  in float64 by ag_knn_resolve_kernel if c1 lies inside the list,
-    //   queued     for stage 2 if the cluster may run past the list or the k-th entry is not provably
-    //              inside the region the tile covers.
-    constexpr bool RESOLVE = (CAP <= AG_KNN_RESOLVE_CAP);
-    float dk = 3.0e38f;
-    int ik = -1;
-#pragma unroll
-    for (int j = 0; j < CAP; ++j)
-      if (j == k - 1) {
-        dk = bd[j];
-        ik = bi[j];
-      }
-    auto err_of = [&](float c2) { return tagged ? ag_chord2_err_tagged(c2) : ag_chord2_err(c2); };
-    const float ek = err_of(dk);
-    const float thr_hi = dk + 3.0f * ek + 4.0e-12f;
-    const bool have_k = active && (ik >= 0);
-    bool queued = active && !have_k;
-    int c1 = k - 1;
-#pragma unroll
-    for (int j = 0; j < CAP; ++j)
-      if (j >= k && bd[j] <= thr_hi) c1 = j;
-    bool exact = false;
-    if (have_k) {
-      if (c1 == CAP - 1) queued = true;
-      if (dk + ek > a.rg_chord2) queued = true;
-      exact = (c1 != k - 1);
-#pragma unroll
-      for (int j = 0; j + 1 < CAP; ++j)
-        if (j + 1 < k) exact = exact || ((bd[j + 1] - bd[j]) <= (err_of(bd[j + 1]) + err_of(bd[j])));
-      if (a.self_query) exact = true;  // the value of the 2nd smallest rdist is needed anyway
-      if (!RESOLVE && exact) queued = true;
-    }
-    const bool done = have_k && !queued;
-    if (done && !exact) {
-      int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
-#pragma unroll
-      for (int j = 0; j < CAP; ++j)
-        if (j < k) o[j] = bi[j];
-      if (a.out_tgt != nullptr) {
-        int32_t* ot = a.out_tgt + static_cast<int64_t>(tid) * k;
-#pragma unroll
-        for (int j = 0; j < CAP; ++j)
-          if (j < k) ot[j] = tid;
-      }
-    }
-    if (RESOLVE) {
-      // targets whose list has to be re-ranked in float64 are appended to a queue (one atomic per
-      // wave); the candidate lists are stored by queue slot, coalesced per rank
-      const bool rec = active && done && exact;
-      const unsigned long long m = __ballot(rec);
-      if (a.self_query) {
-        // every target is re-ranked (the value of its 2nd smallest rdist is needed): slot = target
-        if (active) {
-          a.cand_n[ti] = rec ? c1 + 1 : 0;
-          a.cand_t[ti] = ti;
-          if (rec) {
-#pragma unroll
-            for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + ti] = bi[j];
-          }
-        }
-      } else if (m) {
-        int base = 0;
-        const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        const int q = wi & (a.rq - 1);
-        if (lane == leader) base = atomicAdd(a.rq_count + q * AG_KNN_RQ_STRIDE, __popcll(m));
-        base = __shfl(base, leader, 64) + q * a.rq_cap;
-        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (rec && slot < a.cand_slots) {  // (a queue holds every target that can reach it: the bound only guards the store)
-          a.cand_n[slot] = c1 + 1;
-          a.cand_t[slot] = ti;
-#pragma unroll
-          for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + slot] = bi[j];
-        }
-      }
-    }
-    const unsigned long long mq = __ballot(queued);
-    if (mq) {  // stage-2 queue: one atomic per wave
-      int base = 0;
-      const int leader = __ffsll(static_cast<long long>(mq)) - 1;
-      if (lane == leader) base = atomicAdd(a.queue_count, __popcll(mq));
-      base = __shfl(base, leader, 64);
-      if (queued) a.queue[base + __popcll(mq & ((1ull << lane) - 1ull))] = tid;
-    }
+    ag_knn_classify<CAP, K>(a, active, tagged, tid, ti, wi, bd, bi);
     if (tb + 64 >= t1) break;
+  }
+}
+
+// Stage 1 for target sets far sparser than the source cells (the vertices of a coarse mesh looked up in a fine grid).
+// A wave per target cell would run with a lane or two in use, and merging cells until the lanes fill up makes every
+// lane compare against the sources of the whole merged window.  Here every lane takes one target -- in the caller's
+// order, the targets are not binned at all -- and reads the sources of its own window (the three bands around it,
+// with the half-width of the table: a few dozen sources) straight from the binned array.
+template <int CAP, int K>
+__global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g, const int* __restrict__ sstart) {
+  const int lane = ag_lane();
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int pieces = static_cast<int>((a.nt + 63) >> 6);
+  for (int wi = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wi < pieces; wi += nwaves) {
+    const int64_t t = int64_t(wi) * 64 + lane;
+    const bool active = t < a.nt;
+    const int tid = active ? static_cast<int>(t) : -1;
+    float bd[CAP];
+    int bi[CAP];
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) {
+      bd[j] = 3.0e38f;
+      bi[j] = -1;
+    }
+    if (active) {
+      const float2 tp = a.tgt[tid];
+      const float3 tu = ag_unit_vec_f32(tp.x, tp.y);
+      const double lonw = ag_wrap_lon(static_cast<double>(tp.y));
+      const int band = ag_band_of(g, static_cast<double>(tp.x));
+      const double delta = g.win[band];
+      AgPointWindow pw;
+      pw.b0 = max(band - 1, 0);
+      pw.b1 = min(band + 1, g.nb - 1);
+      pw.lo = lonw - delta;
+      pw.hi = lonw + delta;
+      pw.full = delta < 0.0 || pw.hi - pw.lo >= AG_TWO_PI;
+      // the table entries of the three bands are fetched together, then the cell starts of the six runs (two per
+      // band, the second one empty unless the window wraps): two waits for memory before the scan
+      const int nbands = pw.b1 - pw.b0 + 1;
+      int nc[3], base[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int b = min(pw.b0 + i, pw.b1);
+        nc[i] = g.ncols[b];
+        base[i] = g.off[b];
+      }
+      int first[6], last[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        int c_first = 0, c_last = 0;
+        if ((j >> 1) < nbands) ag_window_cells(pw, nc[j >> 1], (j & 1) != 0, &c_first, &c_last);
+        const bool some = c_last > c_first;
+        first[j] = sstart[base[j >> 1] + (some ? c_first : 0)];
+        last[j] = sstart[base[j >> 1] + (some ? c_last : 0)];
+      }
+#pragma nounroll
+      for (int j = 0; j < 6; ++j) {
+        int p = first[0], end = last[0];
+#pragma unroll
+        for (int r = 1; r < 6; ++r)
+          if (j == r) {
+            p = first[r];
+            end = last[r];
+          }
+        for (; p < end; ++p) {
+          const float4 s = a.spts[p];
+          const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
+          ag_topk_insert<CAP>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(s.w));
+        }
+      }
+    }
+    ag_knn_classify<CAP, K>(a, active, false, tid, tid, wi, bd, bi);
   }
 }
 
@@ -881,7 +966,7 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
     const int n = a.cand_n[slot];
     if (n == 0) continue;
     const int ti = a.cand_t[slot];
-    const int tid = a.tids[ti];
+    const int tid = a.per_target ? ti : a.tids[ti];
     const float2 tp = a.tgt[tid];
     double rr[CAP];
     int bi[CAP];
@@ -981,6 +1066,8 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int nq = *a.queue_count;
   const int k = a.k;
+  // (counted per wave and added up once at the end: atomics on one word are served one after the other)
+  unsigned long long stat_targets = 0, stat_rounds = 0;
   for (int q = wave_global; q < nq; q += nwaves) {
     const int tid = a.queue[q];
     const float2 tpf = a.tgt[tid];
@@ -988,6 +1075,31 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
     const double tlonw = ag_wrap_lon(tlon);
     double R = a.rg;
     int rounds = 0;
+    if (a.bounded) {
+      // A bounded search first counts the sources of the widest window it may look at, a run per lane.  Most targets
+      // that get here have no source anywhere near (the vertices of a global mesh outside the area of the reference
+      // grid) and are done with this one look; those with few sources in reach scan that window at once instead of
+      // working up to it by doubling.
+      int total = 0, nruns = 64;
+      for (int j0 = 0; j0 < nruns; j0 += 64) {
+        int first, last;
+        nruns = ag_lane_range(a.sgrid, a.sstart, tlat, tlonw, a.rmax_window, j0 + lane, &first, &last);
+        total += last - first;
+      }
+#pragma unroll
+      for (int ofs = 32; ofs > 0; ofs >>= 1) total += __shfl_xor(total, ofs, 64);
+      if (total == 0) {
+        if (lane == 0) {
+          for (int j = 0; j < k; ++j) {
+            a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
+            if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
+          }
+        }
+        ++stat_targets;
+        continue;
+      }
+      if (total <= 1024) R = a.rmax_window;
+    }
     for (;;) {
       // a bounded search never looks farther than the bound: the pass at the bound is the last one, and what it
       // does not find is reported as missing
@@ -1047,10 +1159,12 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       R *= 2.0;
       ++rounds;
     }
-    if (lane == 0 && a.stats != nullptr) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), 1ull);
-      if (rounds) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), static_cast<unsigned long long>(rounds));
-    }
+    ++stat_targets;
+    stat_rounds += rounds;
+  }
+  if (lane == 0 && a.stats != nullptr) {
+    if (stat_targets) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), stat_targets);
+    if (stat_rounds) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), stat_rounds);
   }
 }
 
@@ -1084,9 +1198,13 @@ static int ag_knn_cap(int k, bool self_query) {
 // target cell (one wave pass holds 64): m > 0 cuts every source cell into m target cells (dense
 // targets), m < 0 merges -m source cells into one target cell (sparse targets: the window grows by
 // the merged cells, but the lanes of a wave fill up).
-static int ag_knn_tmult(int64_t nt, int nb) {
+static double ag_knn_targets_per_cell(int64_t nt, int nb) {
   const double dlat = AG_PI / nb;
-  const double per_cell = static_cast<double>(nt) / (4.0 * AG_PI / (dlat * dlat));
+  return static_cast<double>(nt) / (4.0 * AG_PI / (dlat * dlat));
+}
+
+static int ag_knn_tmult(int64_t nt, int nb) {
+  const double per_cell = ag_knn_targets_per_cell(nt, nb);
   if (per_cell < 24.0) {
     int g = static_cast<int>(floor(48.0 / (per_cell > 1.0e-9 ? per_cell : 1.0e-9)));
     if (g > 16) g = 16;
@@ -1099,8 +1217,17 @@ static int ag_knn_tmult(int64_t nt, int nb) {
 }
 
 // Dense target sets (what ag_knn_tmult answers with a multiplier >= 1) take their stage-1 descriptors by
-// ranges of 64 binned targets; sparse ones by (merged) target cells.
+// ranges of 64 binned targets; sparse ones by (merged) target cells; the sparsest are not binned at all, every
+// lane of stage 1 takes a target (ag_knn_point_kernel).
 static bool ag_knn_by_range(int tmult) { return tmult >= 1; }
+// Below one target per source cell the per-target kernel wins for every k (4e6 sources, 2.5e5 targets, k = 3: 0.39 ms
+// against 0.81 ms by merged cells; at k = 1, 1.6e4 targets: 0.33 against 0.75 -- what is left is the binning of the
+// sources); from two to three targets per cell on it loses (k = 16, 1e6 targets: 3.4 against 2.9 ms), its lanes
+// reading the same sources one by one that a wave of the cell kernel shares through its tile.
+#define AG_KNN_PER_TARGET_BELOW 1.0
+static bool ag_knn_per_target(int64_t nt, int nb, bool foreign, bool same_set, bool self_query) {
+  return !foreign && !same_set && !self_query && ag_knn_targets_per_cell(nt, nb) < AG_KNN_PER_TARGET_BELOW;
+}
 // descriptors of a search: one per target cell, or one per range (every band ends with a partial one)
 #define AG_KNN_SELF_RANGE 40  // targets per wave when a sparse set is its own target set (about 16 source cells)
 static int64_t ag_knn_windows_ub(int64_t nt, int nb, int tmult, int range_len = 64) {
@@ -1111,6 +1238,7 @@ struct AgKnnWs {
   AgBinned src, tgt;
   double rg;  // angular radius around a target that its window is guaranteed to cover
   int tmult;
+  bool per_target;
   int range_len;
   int* range_off;
   int* queue;
@@ -1141,10 +1269,13 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   // A set queried against itself (the reference distance, the neighbour lists of the Voronoi cells) is binned once:
   // the targets are the binned sources, taken in ranges of 64.  (The carve is the same either way.)
   const bool same_set = w != nullptr && d_src == d_tgt && ns == nt;
+  const bool per_target = ag_knn_per_target(nt, nb, foreign, d_src == d_tgt && ns == nt, self_query);
   int nb_t = nb;
   if (foreign) {  // the caller's binning of the targets: nothing to bin, nothing to carve
     nb_t = ag_kept_bands(nt, kept_tgt.cell);
     if (w) ag_kept_describe(kept_tgt, nt, &w->tgt);
+  } else if (per_target) {
+    if (w) w->tgt = AgBinned();  // (stage 1 reads the targets where the caller has them)
   } else {
     rc = ag_bin_points(c, d_tgt, nt, nb, nb, tmult, false, stream, (w && !same_set) ? &w->tgt : nullptr);
     if (rc) return rc;
@@ -1174,6 +1305,7 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
     w->windows = windows;
     w->range_off = range_off;
     w->tmult = (same_set || foreign) ? 1 : tmult;  // (by ranges of the source binning itself / of the kept binning)
+    w->per_target = per_target;
     w->range_len = (same_set && !foreign && !ag_knn_by_range(tmult)) ? AG_KNN_SELF_RANGE : 64;
     w->queue = queue;
     w->queue_count = queue_count;
@@ -1214,7 +1346,11 @@ static void ag_launch_stage1_k(const AgKnnArgs& a, hipStream_t stream) {
   h.k = a.k;
   h.self_query = a.self_query;
   h.rg_chord2 = a.rg_chord2;
-  AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", (ag_knn_cell_kernel<CAP, K>), dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, h);
+  if (a.per_target) {
+    AG_KERNEL("ag_knn_point_kernel", (ag_knn_point_kernel<CAP, K>), dim3(ag_blocks((a.nt + 63) / 64, 4, 8192)), dim3(256), stream, h, a.sgrid, a.sstart);
+  } else {
+    AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", (ag_knn_cell_kernel<CAP, K>), dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, h);
+  }
   if constexpr (CAP <= AG_KNN_RESOLVE_CAP) {
     const int64_t per_queue = a.self_query ? a.nt : a.rq_cap;
     const int queues = a.self_query ? 1 : a.rq;
@@ -1280,11 +1416,13 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.queue = w.queue;
   a.queue_count = w.queue_count;
   a.windows = w.windows;
-  a.by_range = ag_knn_by_range(w.tmult) ? 1 : 0;
+  a.per_target = w.per_target ? 1 : 0;
+  a.by_range = (!a.per_target && ag_knn_by_range(w.tmult)) ? 1 : 0;
   a.range_len = w.range_len;
-  a.rq = a.by_range ? AG_KNN_RQ : 1;
-  a.rq_cap = a.by_range ? w.rq_cap : static_cast<int>(nt);
-  a.nwin = static_cast<int>(ag_knn_windows_ub(nt, w.tgt.grid.nb, w.tmult, w.range_len));
+  // (every 64 targets of a per-target search are a piece of work that takes the next queue, as the descriptors do)
+  a.rq = (a.by_range || a.per_target) ? AG_KNN_RQ : 1;
+  a.rq_cap = (a.by_range || a.per_target) ? w.rq_cap : static_cast<int>(nt);
+  a.nwin = a.per_target ? 0 : static_cast<int>(ag_knn_windows_ub(nt, w.tgt.grid.nb, w.tmult, w.range_len));
   a.tcell_of = w.tgt.cell_of;
   a.range_off = w.range_off;
   a.self_query = self_query ? 1 : 0;

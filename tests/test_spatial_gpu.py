@@ -263,3 +263,52 @@ def test_knn_edges_entry_point_writes_both_rows(device):
     assert torch.equal(ops.knn_edges(s, t, k), want)
     kept = ops.bin_points(t, 0.05)
     assert torch.equal(ops.knn_edges(s, None, k, tgt_binning=kept), want)
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 20, 40])
+@pytest.mark.parametrize("sources", ["random", "regular"])
+def test_knn_targets_far_sparser_than_the_source_cells(device, sources, k):
+    """Fewer than one target per source cell: the targets are not binned, every lane of stage 1 takes one -- random
+    targets, the poles, targets on a source and targets midway between the nodes of a regular grid (four-way ties),
+    in an order without any locality."""
+    rng = np.random.default_rng(40 + k)
+    src = grids.random_sphere(150_000, seed=41) if sources == "random" else grids.regular(0.5)
+    picks = src[rng.integers(0, len(src), 60)].copy()
+    half = np.deg2rad(0.25)
+    between = grids.regular(0.5)[rng.integers(0, 259_200, 60)] + np.array([half, half], dtype=np.float32)
+    tgt = np.concatenate([grids.random_sphere(400, seed=42), picks, between.astype(np.float32),
+                          np.array([[np.pi / 2, 0.3], [-np.pi / 2, 5.0], [0.0, 0.0], [0.0, 2 * np.pi - 1e-6]], dtype=np.float32)])
+    tgt = tgt[rng.permutation(len(tgt))]
+    res, stats = _knn_case(src, tgt, k, device)
+    edges = ops.knn_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), k)
+    assert torch.equal(edges[0], ops.knn(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), k).reshape(-1))
+    assert torch.equal(edges[1], torch.arange(len(tgt), device=device, dtype=torch.int32).repeat_interleave(k))
+    print("knn per target", sources, k, res["tie_rows"], stats)
+
+
+@pytest.mark.parametrize("bound_km", [2.0, 40.0, 400.0, 3000.0])
+def test_knn_within_a_bound_of_a_dense_regional_set(device, bound_km):
+    """The area mask of a stretched mesh: the vertices of a global mesh looked up in a dense regional set, within a
+    bound.  Most vertices have nothing in reach (one look at the widest window settles them); those near the
+    region find few sources in it (one scan of that window) or many (the window grows by doubling)."""
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(int(bound_km))
+    lat = np.deg2rad(rng.uniform(35.0, 60.0, 400_000))
+    lon = np.deg2rad(rng.uniform(-15.0, 30.0, 400_000))
+    ref = np.stack([lat, lon], axis=1).astype(np.float32)
+    query = rp.tri_nodes(5)[0]
+    bound = bound_km / 6371.0
+    for k in (1, 2):
+        ids, dist = ops.knn(torch.from_numpy(ref).to(device), torch.from_numpy(query).to(device), k, return_dist=True,
+                            max_dist=bound)
+        ids, dist = ids.cpu().numpy(), dist.cpu().numpy()
+        want_d, want_i = NearestNeighbors(metric="haversine").fit(ref).kneighbors(query, n_neighbors=k)
+        inside = want_d <= bound
+        edge = np.abs(want_d - bound) <= 1e-9 * bound
+        assert inside.any() and (~inside).any()
+        keep = inside & ~edge
+        assert np.all(ids[keep] >= 0) and np.all(ids[~inside & ~edge] == -1) and np.all(np.isinf(dist[~inside & ~edge]))
+        np.testing.assert_allclose(dist[keep], want_d[keep], rtol=1e-12, atol=1e-15)
+        differ = keep & (ids != want_i)  # (exact distance ties may list the tied sources in another order)
+        np.testing.assert_allclose(dist[differ], want_d[differ], rtol=1e-12)
