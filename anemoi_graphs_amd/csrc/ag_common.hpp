@@ -322,17 +322,14 @@ __device__ __forceinline__ void ag_for_each_range(const AgGrid& g, const int* __
 
 __device__ __forceinline__ int ag_lane() { return threadIdx.x & 63; }
 
-// The same enumeration for a single target point, one run per lane: run j (two per covered band,
-// the second one empty unless the longitude window wraps) comes back in lane j - j0 as [first,
-// last).  All lanes compute the window; every lane then fetches its own band's cells, so the
-// dependent loads of all bands overlap.  Returns the total number of runs (wave-uniform).
-__device__ __forceinline__ int ag_lane_range(const AgGrid& g, const int* __restrict__ cell_start, double lat,
-                                             double lonw, double R, int j, int* first, int* last) {
-  const AgPointWindow w = ag_point_window(g, lat, lonw, R);
-  const int nruns = 2 * (w.b1 - w.b0 + 1);
+// The same enumeration with a run per lane: run j of the window w (two per covered band, the second one empty
+// unless the longitude interval wraps; 2 (w.b1 - w.b0 + 1) in all) comes back as [first, last).  Lanes that ask
+// for different runs have the dependent table look-ups of all their bands in flight together.
+__device__ __forceinline__ void ag_window_run(const AgGrid& g, const int* __restrict__ cell_start, const AgPointWindow& w,
+                                              int j, int* first, int* last) {
   *first = 0;
   *last = 0;
-  if (j < nruns) {
+  if (j < 2 * (w.b1 - w.b0 + 1)) {
     const int b = w.b0 + (j >> 1);
     const int nc = g.ncols[b];
     const int base = g.off[b];
@@ -343,7 +340,6 @@ __device__ __forceinline__ int ag_lane_range(const AgGrid& g, const int* __restr
       *last = cell_start[base + c_last];
     }
   }
-  return nruns;
 }
 
 #endif  // __HIPCC__

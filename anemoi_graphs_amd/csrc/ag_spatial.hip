@@ -879,7 +879,8 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
 // order, the targets are not binned at all -- and reads the sources of its own window (the three bands around it,
 // with the half-width of the table: a few dozen sources) straight from the binned array.
 template <int CAP, int K>
-__global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g, const int* __restrict__ sstart) {
+__global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g, const int* __restrict__ sstart,
+                                                           const double rmax_window) {
   const int lane = ag_lane();
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int pieces = static_cast<int>((a.nt + 63) >> 6);
@@ -941,7 +942,23 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
         }
       }
     }
-    ag_knn_classify<CAP, K>(a, active, false, tid, tid, wi, bd, bi);
+    // A search with a bound (rmax_window > 0): a target whose window is empty asks whether the latitudes within the
+    // bound hold any source at all -- the bands of the grid are contiguous in the binned array, two look-ups -- and
+    // is done if they do not (of the vertices of a global mesh looked up in a regional grid, most).
+    bool settled = false;
+    if (rmax_window > 0.0 && active && bi[0] < 0) {
+      const double lat = static_cast<double>(a.tgt[tid].x), pad = 1.0e-7 + 1.0e-6 * rmax_window;
+      const int b_first = ag_band_of(g, lat + rmax_window + pad), b_last = ag_band_of(g, lat - rmax_window - pad);
+      settled = sstart[g.off[b_last + 1]] == sstart[g.off[b_first]];
+      if (settled) {
+        const int k = K > 0 ? K : a.k;
+        for (int j = 0; j < k; ++j) {
+          a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
+          if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
+        }
+      }
+    }
+    ag_knn_classify<CAP, K>(a, active && !settled, false, tid, tid, wi, bd, bi);
   }
 }
 
@@ -1080,10 +1097,12 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       // that get here have no source anywhere near (the vertices of a global mesh outside the area of the reference
       // grid) and are done with this one look; those with few sources in reach scan that window at once instead of
       // working up to it by doubling.
-      int total = 0, nruns = 64;
-      for (int j0 = 0; j0 < nruns; j0 += 64) {
+      const AgPointWindow widest = ag_point_window(a.sgrid, tlat, tlonw, a.rmax_window);
+      const int nruns = 2 * (widest.b1 - widest.b0 + 1);
+      int total = 0;
+      for (int j = lane; j < nruns; j += 64) {
         int first, last;
-        nruns = ag_lane_range(a.sgrid, a.sstart, tlat, tlonw, a.rmax_window, j0 + lane, &first, &last);
+        ag_window_run(a.sgrid, a.sstart, widest, j, &first, &last);
         total += last - first;
       }
 #pragma unroll
@@ -1347,7 +1366,8 @@ static void ag_launch_stage1_k(const AgKnnArgs& a, hipStream_t stream) {
   h.self_query = a.self_query;
   h.rg_chord2 = a.rg_chord2;
   if (a.per_target) {
-    AG_KERNEL("ag_knn_point_kernel", (ag_knn_point_kernel<CAP, K>), dim3(ag_blocks((a.nt + 63) / 64, 4, 8192)), dim3(256), stream, h, a.sgrid, a.sstart);
+    AG_KERNEL("ag_knn_point_kernel", (ag_knn_point_kernel<CAP, K>), dim3(ag_blocks((a.nt + 63) / 64, 4, 8192)), dim3(256), stream, h, a.sgrid, a.sstart,
+              a.bounded ? a.rmax_window : 0.0);
   } else {
     AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", (ag_knn_cell_kernel<CAP, K>), dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, h);
   }

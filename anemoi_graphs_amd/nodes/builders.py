@@ -183,12 +183,16 @@ class StretchedTriNodes(StretchedIcosahedronNodes):
 
     def create_nodes(self):
         lam_resolution = max(self.resolutions)
-        _x, _f, base_sorted, _o, base_rank, _e = ops.icosphere(self.global_resolution)
+        if self.global_resolution > lam_resolution:
+            raise ValueError(f"StretchedTriNodes: the global resolution ({self.global_resolution}) must not exceed "
+                             f"the resolution inside the area ({lam_resolution})")
         _x, _f, lam_sorted, _o, lam_rank, level_edges = ops.icosphere(lam_resolution)
-        base = base_sorted[base_rank.long()]  # vertex order
-        lam = lam_sorted[lam_rank.long()]
-        base_out = ~self.area_mask_builder.get_mask(base)
+        lam = lam_sorted[lam_rank.long()]  # vertex order
+        # Refinement keeps the vertices it starts from, at the head of the vertex list: the coarse mesh is the first
+        # 10 * 4**r + 2 vertices of the fine one, and one look-up of the fine vertices answers for both meshes.
+        base = lam[: 10 * 4 ** self.global_resolution + 2]
         lam_in = self.area_mask_builder.get_mask(lam)
+        base_out = ~lam_in[: base.shape[0]]
         coords_all = torch.cat([base[base_out], lam[lam_in]]).contiguous()
         node_ordering = ops.node_order(coords_all)
         coords = coords_all[node_ordering.long()].contiguous()

@@ -191,3 +191,15 @@ def test_node_order_cases(device, case):
         assert np.all(got[1:][tie] < got[:-1][tie])  # equal coordinates: descending id
     else:
         assert np.array_equal(got, want)
+
+
+def test_a_refined_mesh_starts_with_the_vertices_it_refines(device):
+    """What lets StretchedTriNodes answer for its coarse mesh from one look-up of the fine one: the vertices of
+    resolution r are, bit for bit, the first 10 * 4**r + 2 vertices of every finer resolution."""
+    _x, _f, fine_sorted, _o, fine_rank, _e = ops.icosphere(6)
+    fine = fine_sorted[fine_rank.long()]
+    for r in (0, 2, 5):
+        _x, _f, coarse_sorted, _o, coarse_rank, _e = ops.icosphere(r)
+        coarse = coarse_sorted[coarse_rank.long()]
+        assert coarse.shape[0] == 10 * 4 ** r + 2
+        assert torch.equal(coarse, fine[: coarse.shape[0]])
