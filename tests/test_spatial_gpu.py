@@ -163,6 +163,24 @@ def test_radius_long_rows(device, ns, nt, radius):
     print("long rows", radius, res, "max row", rows.max(), "empty rows", int((rows == 0).sum()))
 
 
+def test_radius_rows_of_every_length_in_one_query(device):
+    """Sources clustered around a point: the rows of one query run from empty through a few hundred entries (kept by
+    the count pass), a thousand (sorted in LDS by the fill pass) to tens of thousands (the segmented sort)."""
+    src, tgt = _clustered(300_000, 61), _clustered(2_500, 62)
+    src = src[src[:, 0] > -1.0]  # (no sources around the south pole: empty rows)
+    radius = 0.03
+    res = _radius_case(src, tgt, radius, device)
+    e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius)
+    rows = np.bincount(e[1].cpu().numpy(), minlength=len(tgt))
+    assert (rows == 0).any() and ((rows > 0) & (rows <= 256)).any() and ((rows > 256) & (rows <= 1024)).any() and (rows > 1024).any()
+    # and without any row for the segmented sort
+    few = rows <= 1024
+    e2 = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt[few]).to(device), radius).cpu().numpy()
+    want = e.cpu().numpy()[:, few[e[1].cpu().numpy()]]
+    assert np.array_equal(e2[0], want[0]) and np.array_equal(np.flatnonzero(few)[e2[1]], want[1])
+    print("mixed rows", res, "max row", rows.max(), "rows in LDS", int(((rows > 256) & (rows <= 1024)).sum()))
+
+
 def test_radius_o1280_to_r4(device):
     """A coarse hidden mesh under a dense data grid: every row has thousands of entries."""
     data = grids.octahedral(320)
