@@ -22,11 +22,13 @@ SIGNATURES = {
     "ag_profile_enable": (c_int, [c_int]),
     "ag_profile_filter": (c_int, [ctypes.c_char_p]),
     "ag_profile_collect": (c_int, [ctypes.c_char_p, c_size_t]),
-    "ag_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
-    "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
-    "ag_knn_within": (c_int, [_P, c_int64, _P, c_int64, c_int, c_double, _P, _P, _P, _P, c_size_t, _P]),
-    "ag_nn_maxdist_workspace_bytes": (c_size_t, [c_int64]),
-    "ag_nn_maxdist": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
+    "ag_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_double]),
+    "ag_knn": (c_int, [_P, c_int64, _P, c_int64, c_int, c_double, c_double, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_point_density_workspace_bytes": (c_size_t, [c_int64]),
+    "ag_point_density": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
+    "ag_knn_within": (c_int, [_P, c_int64, _P, c_int64, c_int, c_double, c_double, c_double, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_nn_maxdist_workspace_bytes": (c_size_t, [c_int64, c_double]),
+    "ag_nn_maxdist": (c_int, [_P, c_int64, c_double, _P, _P, c_size_t, _P]),
     "ag_nn_maxdist_static": (c_int, [_P, c_int64, _P, _P]),
     "ag_radius_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ag_radius_count": (c_int, [_P, c_int64, _P, c_int64, c_double, _P, _P, c_size_t, _P]),
@@ -38,9 +40,9 @@ SIGNATURES = {
     "ag_radius_count_binned": (c_int, [_P, c_int64, _P, c_double, _P, c_int64, c_double, _P, _P, c_size_t, _P]),
     "ag_radius_fill_binned": (
         c_int, [_P, c_int64, _P, c_double, _P, c_int64, c_double, _P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
-    "ag_knn_binned_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
-    "ag_knn_binned": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, _P, _P, _P, _P, c_size_t, _P]),
-    "ag_knn_edges": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_knn_binned_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_double]),
+    "ag_knn_binned": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, c_double, _P, _P, _P, _P, c_size_t, _P]),
+    "ag_knn_edges": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, c_double, c_double, _P, _P, _P, _P, c_size_t, _P]),
     "ag_icosphere_sizes": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "ag_icosphere_workspace_bytes": (c_size_t, [c_int]),
     "ag_icosphere": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

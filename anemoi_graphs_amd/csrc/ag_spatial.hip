@@ -1203,6 +1203,21 @@ static double ag_knn_delta(int64_t ns, int k) {
   return d;
 }
 
+// A density as the callers state it: how many times more nodes per steradian the set has, where it has nodes, than
+// the same number of nodes spread over the whole sphere (1 for a global set, 1/f for one that covers the fraction f
+// of the sphere; anything below 1, or not a number, counts as 1).
+static double ag_density(double d) { return d >= 1.0 ? d : 1.0; }
+
+// Bands of the source grid of a k-NN search: cells sized for the density of the sources where they are, but
+// never more than 32 cells per source (a set confined to a speck of the sphere would otherwise ask for a grid of
+// billions of empty cells).
+static int ag_knn_source_bands(int64_t ns, int k, double src_density) {
+  int nb = ag_grid_bands(ag_knn_delta(ns, k) / sqrt(ag_density(src_density)));
+  const double cells_max = 32.0 * static_cast<double>(ns) + 4096.0;
+  const int nb_max = static_cast<int>(sqrt(cells_max * AG_PI / 4.0));  // the grid of nb bands has about 4 nb^2 / pi cells
+  return nb < nb_max ? nb : (nb_max < 1 ? 1 : nb_max);
+}
+
 // list capacity of stage 1: k entries, the (k+1)-th as the boundary witness, room for an ambiguous cluster
 static int ag_knn_cap(int k, bool self_query) {
   if (self_query) return 8;  // self + the 6 near-equidistant neighbours of a mesh node + one witness beyond them
@@ -1217,22 +1232,21 @@ static int ag_knn_cap(int k, bool self_query) {
 // target cell (one wave pass holds 64): m > 0 cuts every source cell into m target cells (dense
 // targets), m < 0 merges -m source cells into one target cell (sparse targets: the window grows by
 // the merged cells, but the lanes of a wave fill up).
-static double ag_knn_targets_per_cell(int64_t nt, int nb) {
+// targets per source cell, where there are targets
+static double ag_knn_targets_per_cell(int64_t nt, int nb, double tgt_density) {
   const double dlat = AG_PI / nb;
-  return static_cast<double>(nt) / (4.0 * AG_PI / (dlat * dlat));
+  return static_cast<double>(nt) * ag_density(tgt_density) / (4.0 * AG_PI / (dlat * dlat));
 }
 
-static int ag_knn_tmult(int64_t nt, int nb) {
-  const double per_cell = ag_knn_targets_per_cell(nt, nb);
+static int ag_knn_tmult(int64_t nt, int nb, double tgt_density) {
+  const double per_cell = ag_knn_targets_per_cell(nt, nb, tgt_density);
   if (per_cell < 24.0) {
     int g = static_cast<int>(floor(48.0 / (per_cell > 1.0e-9 ? per_cell : 1.0e-9)));
     if (g > 16) g = 16;
     return g >= 2 ? -g : 1;
   }
-  int m = static_cast<int>(ceil(per_cell / 48.0));
-  if (m < 1) m = 1;
-  if (m > 64) m = 64;
-  return m;
+  const double cut = ceil(per_cell / 48.0);
+  return cut < 1.0 ? 1 : (cut > 64.0 ? 64 : static_cast<int>(cut));
 }
 
 // Dense target sets (what ag_knn_tmult answers with a multiplier >= 1) take their stage-1 descriptors by
@@ -1244,8 +1258,8 @@ static bool ag_knn_by_range(int tmult) { return tmult >= 1; }
 // sources); from two to three targets per cell on it loses (k = 16, 1e6 targets: 3.4 against 2.9 ms), its lanes
 // reading the same sources one by one that a wave of the cell kernel shares through its tile.
 #define AG_KNN_PER_TARGET_BELOW 1.0
-static bool ag_knn_per_target(int64_t nt, int nb, bool foreign, bool same_set, bool self_query) {
-  return !foreign && !same_set && !self_query && ag_knn_targets_per_cell(nt, nb) < AG_KNN_PER_TARGET_BELOW;
+static bool ag_knn_per_target(int64_t nt, int nb, double tgt_density, bool foreign, bool same_set, bool self_query) {
+  return !foreign && !same_set && !self_query && ag_knn_targets_per_cell(nt, nb, tgt_density) < AG_KNN_PER_TARGET_BELOW;
 }
 // descriptors of a search: one per target cell, or one per range (every band ends with a partial one)
 #define AG_KNN_SELF_RANGE 40  // targets per wave when a sparse set is its own target set (about 16 source cells)
@@ -1274,21 +1288,22 @@ struct AgKnnWs {
 };
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
-                          bool self_query, hipStream_t stream, AgKnnWs* w, const AgKeptBinning& kept_tgt = AgKeptBinning()) {
+                          bool self_query, hipStream_t stream, AgKnnWs* w, double src_density, double tgt_density,
+                          const AgKeptBinning& kept_tgt = AgKeptBinning()) {
   const bool foreign = kept_tgt.buffer != nullptr;
   // (Source cells of half the size for targets from a kept binning -- whose boxes do not line up with the source
   // cells, so that more of a window is cells the box only touches -- were measured: fewer candidates, but more runs
   // to stage per wave, and slower in the end: O1280 decoder 0.178 -> 0.210 ms.)
-  const int nb_std = ag_grid_bands(ag_knn_delta(ns, k));
+  const int nb_std = ag_knn_source_bands(ns, k, src_density);
   const int nb = nb_std;
-  const int tmult = ag_knn_tmult(nt, nb);
+  const int tmult = ag_knn_tmult(nt, nb, tgt_density);
   int rc = ag_bin_points(c, d_src, ns, nb, nb, 1, true, stream, w ? &w->src : nullptr);
   if (rc) return rc;
   if (w) w->rg = 0.98 * (AG_PI / nb_std);
   // A set queried against itself (the reference distance, the neighbour lists of the Voronoi cells) is binned once:
   // the targets are the binned sources, taken in ranges of 64.  (The carve is the same either way.)
   const bool same_set = w != nullptr && d_src == d_tgt && ns == nt;
-  const bool per_target = ag_knn_per_target(nt, nb, foreign, d_src == d_tgt && ns == nt, self_query);
+  const bool per_target = ag_knn_per_target(nt, nb, tgt_density, foreign, d_src == d_tgt && ns == nt, self_query);
   int nb_t = nb;
   if (foreign) {  // the caller's binning of the targets: nothing to bin, nothing to carve
     nb_t = ag_kept_bands(nt, kept_tgt.cell);
@@ -1395,14 +1410,14 @@ static void ag_launch_stage1(const AgKnnArgs& a, hipStream_t stream) {
 
 static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, bool self_query,
                       int32_t* d_out_src, double* d_out_dist, double* d_out_max, int64_t* d_stats, void* d_ws,
-                      size_t ws_bytes, hipStream_t stream, double max_dist = 0.0,
+                      size_t ws_bytes, hipStream_t stream, double src_density, double tgt_density, double max_dist = 0.0,
                       const AgKeptBinning& kept_tgt = AgKeptBinning(), int32_t* d_out_tgt = nullptr) {
   AgCarver sizing(nullptr);
-  ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr, kept_tgt);
+  ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr, src_density, tgt_density, kept_tgt);
   if (ws_bytes < sizing.total()) return ag_fail(AG_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sizing.total());
   AgCarver c(d_ws);
   AgKnnWs w;
-  int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w, kept_tgt);
+  int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w, src_density, tgt_density, kept_tgt);
   if (rc) return rc;
   AgKnnArgs a;
   a.sgrid = w.src.grid;
@@ -1489,15 +1504,20 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   return AG_OK;
 }
 
-extern "C" size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k) {
+extern "C" size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k, double src_density) {
   if (ns < 1 || nt < 0 || k < 1) return 0;
-  AgCarver c(nullptr);
-  ag_knn_prepare(c, nullptr, ns, nullptr, nt > 0 ? nt : 1, k, false, nullptr, nullptr);
-  return c.total();
+  // The carve depends on how the targets are handed to the lanes, which their density decides: by (merged) cells
+  // for the sparsest the set can be, by ranges over ever finer target cells as it gets denser.  The two ends bound
+  // everything between.
+  AgCarver sparse(nullptr), dense(nullptr);
+  ag_knn_prepare(sparse, nullptr, ns, nullptr, nt > 0 ? nt : 1, k, false, nullptr, nullptr, src_density, 1.0);
+  ag_knn_prepare(dense, nullptr, ns, nullptr, nt > 0 ? nt : 1, k, false, nullptr, nullptr, src_density, 1.0e30);
+  return sparse.total() > dense.total() ? sparse.total() : dense.total();
 }
 
-extern "C" int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, int32_t* d_out_src,
-                      double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
+extern "C" int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double src_density,
+                      double tgt_density, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
+                      size_t ws_bytes, void* stream) {
   AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
   AG_REQUIRE(ns >= k, "ag_knn: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn: node counts must fit int32");
@@ -1505,22 +1525,22 @@ extern "C" int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_
   if (nt == 0) return AG_OK;
   AG_REQUIRE(d_src && d_tgt && d_out_src && d_ws, "ag_knn: null pointer");
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), src_density, tgt_density);
 }
 
-extern "C" size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k) {
+extern "C" size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k, double src_density) {
   if (ns < 1 || nt < 1 || k < 1) return 0;
   AgCarver c(nullptr);
   AgKeptBinning sizing;
   sizing.buffer = reinterpret_cast<const void*>(uintptr_t(256));  // (sizing only: never dereferenced)
   sizing.cell = 1.0e-9;                                           // the finest grid the buffer allows: the largest carve
-  ag_knn_prepare(c, nullptr, ns, nullptr, nt, k, false, nullptr, nullptr, sizing);
+  ag_knn_prepare(c, nullptr, ns, nullptr, nt, k, false, nullptr, nullptr, src_density, 1.0, sizing);
   return c.total();
 }
 
 extern "C" int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
-                             double tgt_cell, int k, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
-                             size_t ws_bytes, void* stream) {
+                             double tgt_cell, int k, double src_density, int32_t* d_out_src, double* d_out_dist,
+                             int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_binned: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
   AG_REQUIRE(ns >= k, "ag_knn_binned: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 1, "ag_knn_binned: node counts out of range");
@@ -1531,14 +1551,14 @@ extern "C" int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt,
   kept.buffer = d_tgt_binning;
   kept.cell = tgt_cell;
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
-                    static_cast<hipStream_t>(stream), 0.0, kept);
+                    static_cast<hipStream_t>(stream), src_density, 1.0, 0.0, kept);
 }
 
 // The k-NN graph as an edge list: what ag_knn (ag_knn_binned with a binning of the targets) finds, with the target of
 // every entry written beside it by the same kernels
 extern "C" int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
-                            double tgt_cell, int k, int32_t* d_edge_src, int32_t* d_edge_tgt, int64_t* d_stats, void* d_ws,
-                            size_t ws_bytes, void* stream) {
+                            double tgt_cell, int k, double src_density, double tgt_density, int32_t* d_edge_src,
+                            int32_t* d_edge_tgt, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_edges: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
   AG_REQUIRE(ns >= k, "ag_knn_edges: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn_edges: node counts must fit int32");
@@ -1552,12 +1572,12 @@ extern "C" int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, 
     kept.cell = tgt_cell;
   }
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_edge_src, nullptr, nullptr, d_stats, d_ws, ws_bytes,
-                    static_cast<hipStream_t>(stream), 0.0, kept, d_edge_tgt);
+                    static_cast<hipStream_t>(stream), src_density, tgt_density, 0.0, kept, d_edge_tgt);
 }
 
 extern "C" int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double max_dist,
-                             int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes,
-                             void* stream) {
+                             double src_density, double tgt_density, int32_t* d_out_src, double* d_out_dist,
+                             int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(max_dist > 0.0, "ag_knn_within: the distance bound must be positive (got %g)", max_dist);
   AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_within: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
   AG_REQUIRE(ns >= k, "ag_knn_within: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
@@ -1566,23 +1586,23 @@ extern "C" int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt,
   if (nt == 0) return AG_OK;
   AG_REQUIRE(d_src && d_tgt && d_out_src && d_ws, "ag_knn_within: null pointer");
   return ag_knn_run(d_src, ns, d_tgt, nt, k, false, d_out_src, d_out_dist, nullptr, d_stats, d_ws, ws_bytes,
-                    static_cast<hipStream_t>(stream), max_dist);
+                    static_cast<hipStream_t>(stream), src_density, tgt_density, max_dist);
 }
 
-extern "C" size_t ag_nn_maxdist_workspace_bytes(int64_t n) {
+extern "C" size_t ag_nn_maxdist_workspace_bytes(int64_t n, double density) {
   if (n < 2) return 0;
   AgCarver c(nullptr);
-  ag_knn_prepare(c, nullptr, n, nullptr, n, 2, true, nullptr, nullptr);
+  ag_knn_prepare(c, nullptr, n, nullptr, n, 2, true, nullptr, nullptr, density, density);
   return c.total();
 }
 
-extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, size_t ws_bytes,
-                             void* stream) {
+extern "C" int ag_nn_maxdist(const float* d_pts, int64_t n, double density, double* d_out_max, void* d_ws,
+                             size_t ws_bytes, void* stream) {
   AG_REQUIRE(n >= 2, "ag_nn_maxdist: needs at least 2 points (n=%lld)", static_cast<long long>(n));
   AG_REQUIRE(n < (int64_t(1) << 31), "ag_nn_maxdist: node count must fit int32");
   AG_REQUIRE(d_pts && d_out_max && d_ws, "ag_nn_maxdist: null pointer");
   return ag_knn_run(d_pts, n, d_pts, n, 2, true, nullptr, nullptr, d_out_max, nullptr, d_ws, ws_bytes,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), density, density);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1617,7 +1637,7 @@ extern "C" int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out
   AG_REQUIRE(n <= AG_NN_MAXDIST_STATIC_MAX_N,
              "ag_nn_maxdist_static: %lld points exceed the %d the built-in scratch array holds; use ag_nn_maxdist with a "
              "workspace", static_cast<long long>(n), AG_NN_MAXDIST_STATIC_MAX_N);
-  const size_t need = ag_nn_maxdist_workspace_bytes(n);
+  const size_t need = ag_nn_maxdist_workspace_bytes(n, 1.0);  // (the grid of a set spread over the sphere)
   AG_REQUIRE(need <= AG_STATIC_SCRATCH_BYTES, "ag_nn_maxdist_static: %zu bytes of scratch needed, %zu built in", need,
              AG_STATIC_SCRATCH_BYTES);
   AG_REQUIRE(d_pts && d_out_max, "ag_nn_maxdist_static: null pointer");
@@ -1627,7 +1647,94 @@ extern "C" int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out
   // (nothing in the scratch has to be zero on entry: the kernels of the query clear the counters, queue heads and
   // scan states they use, whatever an earlier call left there)
   return ag_knn_run(d_pts, n, d_pts, n, 2, true, nullptr, nullptr, d_out_max, nullptr, scratch, AG_STATIC_SCRATCH_BYTES,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), 1.0, 1.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// density of a node set, for the callers that do not know it
+// ---------------------------------------------------------------------------------------------
+// The sphere is cut into `cells` cells of equal area (rows of equal height in sin(latitude), columns of equal
+// width in longitude), every node is counted into its cell, and the answer is the mean over the NODES of the
+// density around them, relative to the density of as many nodes spread over the sphere:
+//   cells * sum_c n_c (n_c - 1) / (n (n - 1))
+// (n_c - 1 instead of n_c: an unbiased estimate of the squared cell densities, so that a small uniform set, most of
+// whose cells hold one node or none, still comes out at 1).  1 for a global grid, 1/f for a grid that covers the
+// fraction f of the sphere, about 1/f_dense for a stretched grid with most of its nodes in the fraction f_dense.
+#define AG_DENSITY_MAX_CELLS 32768
+
+static void ag_density_grid(int64_t n, int* rows, int* cols) {
+  int r = 8;  // rows x 2 rows cells, about 64 nodes per cell of a uniform set
+  while (2 * (2 * r) * (2 * r) <= n / 64 && 2 * (2 * r) * (2 * r) <= AG_DENSITY_MAX_CELLS) r *= 2;
+  *rows = r;
+  *cols = 2 * r;
+}
+
+__global__ void ag_density_count_kernel(const float2* __restrict__ pts, int64_t n, int rows, int cols,
+                                        int* __restrict__ count) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const float2 p = pts[i];
+    const double z = ag_sin_f64(static_cast<double>(p.x));
+    const int r = min(max(static_cast<int>((1.0 - z) * 0.5 * rows), 0), rows - 1);
+    const int c = min(max(static_cast<int>(ag_wrap_lon(static_cast<double>(p.y)) * AG_INV_TWO_PI * cols), 0), cols - 1);
+    const int cell = r * cols + c;
+    // consecutive nodes mostly share a cell: the first lane of every run of equal cells counts for the run
+    // (lanes past the end of the array are the highest lanes of the last wave)
+    const int lane = ag_lane();
+    const int prev = __shfl_up(cell, 1, 64);
+    const bool head = (lane == 0) || (prev != cell);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long active = __ballot(1);
+    const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
+    const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1) : (64 - __clzll(static_cast<long long>(active)));
+    if (head) atomicAdd(&count[cell], run_end - lane);
+  }
+}
+
+__global__ __launch_bounds__(1024) void ag_density_finish_kernel(const int* __restrict__ count, int cells, int64_t n,
+                                                                 double* __restrict__ out) {
+  __shared__ double partial[1024];
+  double sum = 0.0;
+  for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+    const double m = static_cast<double>(count[c]);
+    sum += m * (m - 1.0);
+  }
+  partial[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 512; d > 0; d >>= 1) {
+    if (threadIdx.x < d) partial[threadIdx.x] += partial[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double nn = static_cast<double>(n) * (static_cast<double>(n) - 1.0);
+    double density = nn > 0.0 ? cells * partial[0] / nn : 1.0;
+    if (!(density >= 1.0)) density = 1.0;
+    if (density > cells) density = cells;
+    *out = density;
+  }
+}
+
+extern "C" size_t ag_point_density_workspace_bytes(int64_t n) {
+  (void)n;
+  return sizeof(int) * AG_DENSITY_MAX_CELLS + 256;
+}
+
+extern "C" int ag_point_density(const float* d_pts, int64_t n, double* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+  AG_REQUIRE(n >= 1, "ag_point_density: no points");
+  AG_REQUIRE(d_pts && d_out && d_ws, "ag_point_density: null pointer");
+  if (ws_bytes < ag_point_density_workspace_bytes(n)) return ag_fail(AG_ERR_WORKSPACE, "ag_point_density: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rows, cols;
+  ag_density_grid(n, &rows, &cols);
+  AgCarver c(d_ws);
+  int* count = c.take<int>(AG_DENSITY_MAX_CELLS);
+  int rc = ag_zero_i32(count, rows * cols, s);
+  if (rc) return rc;
+  AG_KERNEL("ag_density_count_kernel", ag_density_count_kernel, dim3(ag_blocks(n, 256, 8192)), dim3(256), s,
+            reinterpret_cast<const float2*>(d_pts), n, rows, cols, count);
+  AG_LAUNCH_CHECK();
+  AG_KERNEL("ag_density_finish_kernel", ag_density_finish_kernel, dim3(1), dim3(1024), s, count, rows * cols, n, d_out);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,6 +31,16 @@ import math
 import torch
 
 from . import ops as _hip_ops
+
+
+def _global_sources(backend) -> dict:
+    """What the HIP searches are told about a hidden mesh that covers the sphere (``ops.point_density`` = 1), so that
+    they need not measure it; other backends take no such argument."""
+    return {"src_density": 1.0} if backend is _hip_ops else {}
+
+
+def _global_set(backend) -> dict:
+    return {"density": 1.0} if backend is _hip_ops else {}
 from . import settings
 from .hetero import HeteroData
 
@@ -341,7 +351,7 @@ class ShardedGraphBuilder:
         # (the target row of a k-NN edge list is 0,0,0,1,1,1,... whatever the band).  It needs nothing from
         # the other ranks and its gather is the largest transfer of the build, so it is started before the
         # reference distance and the encoder search, which then run while the ids travel.
-        ids = be.knn(hidden, self.data_local, self.k).reshape(-1)
+        ids = be.knn(hidden, self.data_local, self.k, **_global_sources(be)).reshape(-1)
         band_sizes = [(self.bounds[i + 1] - self.bounds[i]) * self.k for i in range(W)]
         dec_all = torch.empty((2, self.n_data * self.k), dtype=torch.int32, device=dev)
         dec_gather = comm.all_gather_rows_async([ids], band_sizes, out=[dec_all[0]])
@@ -350,7 +360,7 @@ class ShardedGraphBuilder:
 
         # ---- encoder: hidden targets of my band, data sources = my band + halo
         # (band limits by binary search on the device; one host synchronisation for all of them)
-        radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
+        radius_t = be.nn_maxdist(hidden, **_global_set(be)).to(dev).double() * self.cutoff_factor
         reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
         nd = self.data_local.shape[0]
         neg_hlat = (-hidden[:, 0]).contiguous()
@@ -618,7 +628,7 @@ class BandGraphBuilder:
                 self._processor_edges(graph, proc_name, hidden, rank_map, level_edges, mark)
 
         # ---- sources of the encoder: my band plus the rows my neighbours send
-        radius_t = be.nn_maxdist(hidden).to(dev).double() * self.cutoff_factor
+        radius_t = be.nn_maxdist(hidden, **_global_set(be)).to(dev).double() * self.cutoff_factor
         reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
         neg_hlat = (-hidden[:, 0]).contiguous()
         zero = torch.zeros((), dtype=torch.int64, device=dev)
@@ -652,14 +662,14 @@ class BandGraphBuilder:
             own_cell = ((2.0 * (self.k + 1) + 2.0) * 4.0 / max(nh, 1)) ** 0.5
             binned = kept is not None and sources.shape[0] <= nd + nd // 8 and kept.cell <= 1.5 * own_cell
             if binned and sources.shape[0] == nd:  # no halo rows: the search writes the edge list itself
-                dec = be.knn_edges(hidden, None, self.k, tgt_binning=kept)
+                dec = be.knn_edges(hidden, None, self.k, tgt_binning=kept, **_global_sources(be))
             else:
                 dec = torch.empty((2, nd * self.k), dtype=torch.int32, device=dev)
                 if binned:
-                    ids = be.knn(hidden, None, self.k, tgt_binning=kept)
+                    ids = be.knn(hidden, None, self.k, tgt_binning=kept, **_global_sources(be))
                     dec[0] = ids[before:before + nd].reshape(-1)
                 else:
-                    dec[0] = be.knn(hidden, self.data_band, self.k).reshape(-1)
+                    dec[0] = be.knn(hidden, self.data_band, self.k, **_global_sources(be)).reshape(-1)
                 be.row_ids(nd, self.k, dev, out=dec[1])
             mark("decoder_search")
             if self.attributes:

@@ -98,6 +98,19 @@ class BaseEdgeBuilder(ABC):
         return graph
 
 
+def node_density(nodes: NodeStorage) -> float:
+    """Density of a node set (``ops.point_density``): the value its builder left with it -- a mesh knows the share
+    of the sphere it covers -- else measured once and kept with the set (a private attribute)."""
+    x = torch.as_tensor(nodes.x)
+    key = ops.tensor_key(x)
+    kept = nodes["_density"] if "_density" in nodes else None
+    if isinstance(kept, tuple) and kept[0] == key:
+        return kept[1]
+    value = ops.point_density(x)
+    nodes["_density"] = (key, value)
+    return value
+
+
 class NodeMaskingMixin:
     """Masking of source/target nodes (edges/builder.py:159-193): the search runs on the compacted
     node sets and the ids are mapped back through the compaction maps on the device."""
@@ -150,11 +163,17 @@ class KNNEdges(BaseEdgeBuilder, NodeMaskingMixin):
             # cut-off encoder) are taken in that order, if its cells are not coarser than this search's own
             kept = kept_binning(target_nodes, None)
             n_src = int(torch.as_tensor(source_nodes.x).shape[0])
-            own_cell = math.sqrt((2.0 * (k + 1) + 2.0) * 4.0 / max(n_src, 1))
+            src_density = node_density(source_nodes)
+            own_cell = math.sqrt((2.0 * (k + 1) + 2.0) * 4.0 / (max(n_src, 1) * src_density))
             if kept is not None and kept.cell <= 1.5 * own_cell:
-                return ops.knn_edges(ops.coords(source_nodes.x, kept.x.device), None, k, tgt_binning=kept)
+                return ops.knn_edges(ops.coords(source_nodes.x, kept.x.device), None, k, tgt_binning=kept,
+                                     src_density=src_density)
         source_coords, target_coords = self.get_node_coordinates(source_nodes, target_nodes)
-        edge_index = ops.knn_edges(source_coords, target_coords, k)  # per target: ascending distance
+        # (masked node sets are measured: the mask may pick any part of the set)
+        edge_index = ops.knn_edges(  # per target: ascending distance
+            source_coords, target_coords, k,
+            src_density=node_density(source_nodes) if self.source_mask_attr_name is None else None,
+            tgt_density=node_density(target_nodes) if self.target_mask_attr_name is None else None)
         return self.undo_masking(edge_index, source_nodes, target_nodes)
 
 
@@ -186,7 +205,7 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
         kept = target_nodes["_reference_distance"] if "_reference_distance" in target_nodes else None
         if mask is None and isinstance(kept, tuple) and kept[0] == key:
             return kept[1] * self.cutoff_factor
-        target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask)
+        target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask, density=node_density(target_nodes))
         if mask is None:
             target_nodes["_reference_distance"] = (key, target_grid_reference_distance)
         return target_grid_reference_distance * self.cutoff_factor

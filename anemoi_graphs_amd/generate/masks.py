@@ -54,9 +54,10 @@ class KNNAreaMaskBuilder:
             'Fitting %s with %d reference nodes from "%s".', self.__class__.__name__, len(coords_rad), reference_mask_str
         )
 
-    def get_mask(self, coords_rad) -> torch.Tensor:
+    def get_mask(self, coords_rad, density: float | None = None) -> torch.Tensor:
         """bool [N] device tensor: distance to the nearest reference node, in km, within the margin
-        (masks.py:94-99)."""
+        (masks.py:94-99).  ``density``: of the queried points when the caller knows it (``ops.point_density``; 1 for
+        the vertices of a global mesh), else it is measured."""
         assert self._reference is not None, "fit() or fit_coords() must be called first."
         query = ops.coords(coords_rad if isinstance(coords_rad, torch.Tensor) else np.asarray(coords_rad),
                            self._reference.device)
@@ -64,5 +65,5 @@ class KNNAreaMaskBuilder:
         # the search stops at the margin (a vertex with nothing that close comes back with an infinite distance),
         # so vertices far from a regional reference set cost a few empty window look-ups instead of a scan.
         bound = float(self.margin_radius_km) / EARTH_RADIUS * (1.0 + 1.0e-9)
-        _ids, dists = ops.knn(self._reference, query, 1, return_dist=True, max_dist=bound)
+        _ids, dists = ops.knn(self._reference, query, 1, return_dist=True, max_dist=bound, tgt_density=density)
         return dists[:, 0] * EARTH_RADIUS <= self.margin_radius_km

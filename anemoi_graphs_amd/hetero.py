@@ -51,6 +51,11 @@ except ImportError:
                 self._stores[key] = NodeStorage()
             return self._stores[key]
 
+        def __delitem__(self, key):
+            if isinstance(key, list):
+                key = tuple(key)
+            del self._stores[key]
+
         def __contains__(self, key):
             return key in self._stores
 

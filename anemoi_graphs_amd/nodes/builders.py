@@ -104,9 +104,18 @@ class IcosahedralNodes(BaseNodeBuilder, ABC):
             "resolutions", "nx_graph", "node_ordering", "area_mask_builder",
         }
 
+    # nodes per steradian where the mesh has nodes, relative to as many nodes spread over the sphere
+    # (ops.point_density): a mesh knows what share of the sphere it covers, so nobody has to measure it
+    density: float = 1.0
+
     def get_coordinates(self) -> torch.Tensor:
         self.nx_graph, coords_rad, self.node_ordering = self.create_nodes()
         return coords_rad
+
+    def register_nodes(self, graph: HeteroData) -> HeteroData:
+        graph = super().register_nodes(graph)
+        graph[self.name]["_density"] = (ops.tensor_key(torch.as_tensor(graph[self.name].x)), float(self.density))
+        return graph
 
     @abstractmethod
     def create_nodes(self): ...
@@ -152,9 +161,10 @@ class LimitedAreaTriNodes(LimitedAreaIcosahedralNodes):
     def create_nodes(self):
         resolution = max(self.resolutions)
         _xyz, _faces, latlon, order, _rank, level_edges = ops.icosphere(resolution)
-        keep = self.area_mask_builder.get_mask(latlon)  # in node order
+        keep = self.area_mask_builder.get_mask(latlon, density=1.0)  # in node order
         coords = latlon[keep].contiguous()
         node_ordering = order[keep].contiguous()
+        self.density = latlon.shape[0] / max(int(coords.shape[0]), 1)  # (the vertices of the sphere over those kept)
         rank = torch.full((order.numel(),), -1, dtype=torch.int32, device=order.device)
         rank[node_ordering.long()] = torch.arange(node_ordering.numel(), dtype=torch.int32, device=order.device)
         mesh = IcosahedralMesh(resolution, node_ordering, rank, level_edges, (rank >= 0).to(torch.uint8))
@@ -191,13 +201,19 @@ class StretchedTriNodes(StretchedIcosahedronNodes):
         # Refinement keeps the vertices it starts from, at the head of the vertex list: the coarse mesh is the first
         # 10 * 4**r + 2 vertices of the fine one, and one look-up of the fine vertices answers for both meshes.
         base = lam[: 10 * 4 ** self.global_resolution + 2]
-        lam_in = self.area_mask_builder.get_mask(lam)
+        lam_in = self.area_mask_builder.get_mask(lam, density=1.0)
         base_out = ~lam_in[: base.shape[0]]
         coords_all = torch.cat([base[base_out], lam[lam_in]]).contiguous()
         node_ordering = ops.node_order(coords_all)
         coords = coords_all[node_ordering.long()].contiguous()
         dev = lam.device
         n_base = int(base_out.sum().item())
+        # two densities, the coarse mesh outside the area (the share `outside` of the sphere) and the fine one inside:
+        # the mean over the nodes of the density around them
+        n_all, n_fine = int(coords_all.shape[0]), int(coords_all.shape[0]) - n_base
+        outside = n_base / base.shape[0]
+        if 0.0 < outside < 1.0 and n_all > 0:
+            self.density = max(1.0, (n_base ** 2 / outside + n_fine ** 2 / (1.0 - outside)) / n_all ** 2)
         # mesh vertex -> id in the concatenation (coarse vertices are the first vertices of the fine mesh)
         cid = torch.full((lam.shape[0],), -1, dtype=torch.int64, device=dev)
         cid[torch.nonzero(base_out).squeeze(1)] = torch.arange(n_base, device=dev)

@@ -6,6 +6,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -132,6 +133,42 @@ def tensor_key(t: torch.Tensor):
     return (t.data_ptr(), tuple(t.shape), t.dtype, str(t.device), t._version)
 
 
+_DENSITIES: dict = {}  # id(tensor) -> (weak reference, version, density): valid while that very tensor is alive and unchanged
+
+
+def point_density(x: torch.Tensor) -> float:
+    """How many times more nodes per steradian the set has, where it has nodes, than as many nodes spread over the
+    sphere (``ag_point_density``): 1 for a global grid, 1/f for a regional one covering the fraction f of the
+    sphere.  What the k-NN searches size their cells with.  Measured on the device and read back (one
+    synchronisation), once per tensor object."""
+    src = torch.as_tensor(x)
+    if src.shape[0] < 1024:
+        return 1.0
+    found = _DENSITIES.get(id(src))
+    if found is not None and found[0]() is src and found[1] == src._version:
+        return found[2]
+    lib = _lib.load()
+    dev = device_of(src)
+    xd = coords(src, dev)
+    n = xd.shape[0]
+    with _on(dev):
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        ws = _workspace(lib.ag_point_density_workspace_bytes(n), dev)
+        _lib.check(lib.ag_point_density(_ptr(xd), n, _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "ag_point_density")
+        value = float(out.item())
+    if len(_DENSITIES) >= 64:
+        for dead in [k for k, v in _DENSITIES.items() if v[0]() is None]:
+            del _DENSITIES[dead]
+        if len(_DENSITIES) >= 64:
+            _DENSITIES.clear()
+    _DENSITIES[id(src)] = (weakref.ref(src), src._version, value)
+    return value
+
+
+def _density(given: float | None, x: torch.Tensor) -> float:
+    return float(given) if given is not None else point_density(x)
+
+
 def radius_cell(ns: int, radius: float) -> float:
     """Cell size a cut-off search of this radius over ``ns`` sources works best with."""
     return float(_lib.load().ag_radius_cell(int(ns), float(radius)))
@@ -154,11 +191,17 @@ def bin_points(x: torch.Tensor, cell: float, device: torch.device | None = None)
 
 
 def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False, return_stats: bool = False,
-        max_dist: float | None = None, tgt_binning: Binning | None = None):
+        max_dist: float | None = None, tgt_binning: Binning | None = None, src_density: float | None = None,
+        tgt_density: float | None = None):
     """ids [Nt,k] int32 of the k nearest sources of every target, ascending distance.  ``max_dist`` (radians):
-    neighbours farther than that are not searched for; their ids are -1 and their distances infinity."""
+    neighbours farther than that are not searched for; their ids are -1 and their distances infinity.
+    ``src_density`` / ``tgt_density``: see ``point_density`` (measured when not given; they decide how fast the
+    search runs, not what it returns)."""
     lib = _lib.load()
     dev = device_of(src, tgt) if tgt_binning is None else tgt_binning.x.device
+    src_density = _density(src_density, src)
+    if tgt_binning is None:
+        tgt_density = _density(tgt_density, tgt)
     src = coords(src, dev)
     tgt = coords(tgt, dev) if tgt_binning is None else tgt_binning.x
     ns, nt = src.shape[0], tgt.shape[0]
@@ -171,25 +214,27 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
         stats = torch.zeros(4, dtype=torch.int64, device=dev)
         if tgt_binning is not None and max_dist is None and nt > 0:
             tgt_binning.wait()
-            ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k), dev)
+            ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k, src_density), dev)
             _lib.check(
-                lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k, _ptr(out),
-                                  _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev)),
+                lib.ag_knn_binned(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer), tgt_binning.cell, k, src_density,
+                                  _ptr(out), _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_knn_binned",
             )
             res = (out,) + ((dist,) if return_dist else ()) + ((stats,) if return_stats else ())
             return res[0] if len(res) == 1 else res
-        ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k), dev)
+        if tgt_density is None:  # (a bounded search with a binning of the targets: they are searched unbinned)
+            tgt_density = point_density(tgt)
+        ws = _workspace(lib.ag_knn_workspace_bytes(ns, nt, k, src_density), dev)
         if max_dist is None:
             _lib.check(
-                lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, _ptr(out), _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(),
-                           _stream(dev)),
+                lib.ag_knn(_ptr(src), ns, _ptr(tgt), nt, k, src_density, tgt_density, _ptr(out), _ptr(dist), _ptr(stats),
+                           _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_knn",
             )
         else:
             _lib.check(
-                lib.ag_knn_within(_ptr(src), ns, _ptr(tgt), nt, k, float(max_dist), _ptr(out), _ptr(dist), _ptr(stats),
-                                  _ptr(ws), ws.numel(), _stream(dev)),
+                lib.ag_knn_within(_ptr(src), ns, _ptr(tgt), nt, k, float(max_dist), src_density, tgt_density, _ptr(out),
+                                  _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_knn_within",
             )
     res = (out,)
@@ -200,11 +245,15 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
     return res[0] if len(res) == 1 else res
 
 
-def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning | None = None) -> torch.Tensor:
+def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning | None = None,
+              src_density: float | None = None, tgt_density: float | None = None) -> torch.Tensor:
     """edge_index [2, Nt*k] int32 of the k-NN graph: row 0 the k nearest sources of every target
-    (ascending distance), row 1 the target id.  ``tgt_binning``: a kept binning of the targets."""
+    (ascending distance), row 1 the target id.  ``tgt_binning``: a kept binning of the targets.
+    ``src_density`` / ``tgt_density``: as for ``knn``."""
     lib = _lib.load()
     dev = device_of(src, tgt) if tgt_binning is None else tgt_binning.x.device
+    src_density = _density(src_density, src)
+    tgt_density = 1.0 if tgt_binning is not None else _density(tgt_density, tgt)
     src = coords(src, dev)
     tgt = coords(tgt, dev) if tgt_binning is None else tgt_binning.x
     ns, nt = src.shape[0], tgt.shape[0]
@@ -215,12 +264,13 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning
         binned = tgt_binning is not None and nt > 0
         if binned:
             tgt_binning.wait()
-        ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k) if binned else lib.ag_knn_workspace_bytes(ns, nt, k), dev)
+        ws = _workspace(lib.ag_knn_binned_workspace_bytes(ns, nt, k, src_density) if binned
+                        else lib.ag_knn_workspace_bytes(ns, nt, k, src_density), dev)
         # (both rows come from the search kernels: the target row needs no pass of its own)
         _lib.check(
             lib.ag_knn_edges(_ptr(src), ns, _ptr(tgt), nt, _ptr(tgt_binning.buffer) if binned else None,
-                             tgt_binning.cell if binned else 0.0, k, _ptr(edge_index[0]), _ptr(edge_index[1]), None,
-                             _ptr(ws), ws.numel(), _stream(dev)),
+                             tgt_binning.cell if binned else 0.0, k, src_density, tgt_density, _ptr(edge_index[0]),
+                             _ptr(edge_index[1]), None, _ptr(ws), ws.numel(), _stream(dev)),
             "ag_knn_edges",
         )
     return edge_index
@@ -239,18 +289,20 @@ def row_ids(rows: int, k: int, device: torch.device, out: torch.Tensor | None = 
     return out
 
 
-def nn_maxdist(x: torch.Tensor) -> torch.Tensor:
-    """0-dim float64 device tensor: max over the nodes of the distance to the nearest other node."""
+def nn_maxdist(x: torch.Tensor, density: float | None = None) -> torch.Tensor:
+    """0-dim float64 device tensor: max over the nodes of the distance to the nearest other node.
+    ``density``: of the node set, see ``point_density`` (measured when not given)."""
     lib = _lib.load()
     dev = device_of(x)
+    density = _density(density, x)
     x = coords(x, dev)
     n = x.shape[0]
     if n < 2:
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = 2, n_samples_fit = {n}")
     with _on(dev):
         out = torch.zeros((), dtype=torch.float64, device=dev)
-        ws = _workspace(lib.ag_nn_maxdist_workspace_bytes(n), dev)
-        _lib.check(lib.ag_nn_maxdist(_ptr(x), n, _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "ag_nn_maxdist")
+        ws = _workspace(lib.ag_nn_maxdist_workspace_bytes(n, density), dev)
+        _lib.check(lib.ag_nn_maxdist(_ptr(x), n, density, _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "ag_nn_maxdist")
     return out
 
 

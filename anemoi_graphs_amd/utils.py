@@ -30,14 +30,16 @@ def place(t: torch.Tensor, like: torch.Tensor | None = None) -> torch.Tensor:
     return to_host(t)
 
 
-def get_grid_reference_distance(coords_rad: torch.Tensor, mask: torch.Tensor | None = None) -> float:
+def get_grid_reference_distance(coords_rad: torch.Tensor, mask: torch.Tensor | None = None,
+                                density: float | None = None) -> float:
     """Maximum over the nodes of the distance to the nearest other node (utils.py:44-63).
 
-    As in the reference the mask is only checked for shape, never applied (utils.py:32-39)."""
+    As in the reference the mask is only checked for shape, never applied (utils.py:32-39).  ``density``: of the
+    node set when the caller knows it (``ops.point_density``), else it is measured."""
     assert mask is None or mask.shape == (coords_rad.shape[0], 1), (
         "Mask must have the same shape as the number of nodes."
     )
-    value = float(ops.nn_maxdist(coords_rad).item())
+    value = float(ops.nn_maxdist(coords_rad, density=density).item())
     if value == 0.0:
         # every node coincides with another one: the reference takes dists[dists > 0].max() of an empty
         # selection, which numpy refuses with exactly this error (utils.py:61-63)

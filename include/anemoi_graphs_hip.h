@@ -55,28 +55,47 @@ int ag_profile_collect(char* buf, size_t buf_bytes);
  * 2*asin(sqrt(rdist)) in radians.  d_stats (nullable, int64[4]) receives: [0] targets resolved
  * by the float64 wave-per-target path, [1] passes of that path beyond the first window.
  * Requires 1 <= k <= ns and k <= AG_KNN_MAX_K.
+ *
+ * src_density, tgt_density (no counterpart in the reference, whose ball tree adapts to its points by itself):
+ * how many times more nodes per steradian a set has, where it has nodes, than the same number of nodes spread
+ * over the whole sphere -- 1 for a global grid or mesh, 1/f for a regional one that covers the fraction f of the
+ * sphere; values below 1 count as 1.  The searches bin the sources into cells sized for the density given (a
+ * regional set binned as if it were global crowds thirty times the intended sources into every cell) and choose
+ * how the targets are handed to the lanes from theirs.  The densities only decide how fast a search runs; its
+ * results are the same for any values.  ag_point_density measures the density of a set whose extent the caller
+ * does not know.  The workspace is sized for the source density that the search is then given.
  */
 #define AG_KNN_MAX_K 64
-size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k);
-int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, int32_t* d_out_src,
-           double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
+size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k, double src_density);
+int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double src_density,
+           double tgt_density, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes,
+           void* stream);
+
+/* The density of a node set as the k-NN entry points take it: the mean over the nodes of the density around them
+ * (counted in up to 32768 cells of equal area), relative to that of as many nodes spread over the sphere.  1 for
+ * a global grid, 1/f for a grid that covers the fraction f of the sphere, about the value of its dense part for a
+ * stretched grid.  Writes one float64 to *d_out (device memory). */
+size_t ag_point_density_workspace_bytes(int64_t n);
+int ag_point_density(const float* d_pts, int64_t n, double* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ag_knn that does not look beyond max_dist (radians): an entry whose neighbour would be farther than that is
  * -1 in d_out_src and +infinity in d_out_dist.  Replaces `kneighbors(coords, n_neighbors=1)` followed by the
  * threshold `dists * EARTH_RADIUS <= margin_radius_km` of KNNAreaMaskBuilder.get_mask (generate/masks.py:94-99):
  * the mask only asks whether a reference node lies within the margin, so mesh vertices far from a regional
- * reference set need no search over the whole sphere.  Workspace: ag_knn_workspace_bytes(ns, nt, k). */
+ * reference set need no search over the whole sphere.  Workspace: ag_knn_workspace_bytes(ns, nt, k, src_density). */
 int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double max_dist,
-                  int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
+                  double src_density, double tgt_density, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats,
+                  void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Grid reference distance.
  * Replaces utils.get_grid_reference_distance (utils.py:61-63): kneighbors(pts, 2) on the set
  * itself and dists[dists > 0].max().  Writes the float64 result (radians) to *d_out_max
- * (0.0 if no positive distance exists).
+ * (0.0 if no positive distance exists).  density: of the set, as for ag_knn.
  */
-size_t ag_nn_maxdist_workspace_bytes(int64_t n);
-int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, size_t ws_bytes, void* stream);
+size_t ag_nn_maxdist_workspace_bytes(int64_t n, double density);
+int ag_nn_maxdist(const float* d_pts, int64_t n, double density, double* d_out_max, void* d_ws, size_t ws_bytes,
+                  void* stream);
 
 /* ag_nn_maxdist without a workspace argument, for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
@@ -86,7 +105,7 @@ int ag_nn_maxdist(const float* d_pts, int64_t n, double* d_out_max, void* d_ws, 
  * device looks the array's address up (hipGetSymbolAddress), so make that call outside a capture.  Same
  * result as ag_nn_maxdist, bit for bit.  All calls on one GPU share that GPU's array: calls that overlap on one
  * GPU (two streams, two threads) race; successive calls on one stream do not.  Call with the device of
- * `stream` current. */
+ * `stream` current.  The set is binned as one spread over the sphere (density 1). */
 #define AG_NN_MAXDIST_STATIC_MAX_N 262144
 int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out_max, void* stream);
 
@@ -122,7 +141,7 @@ int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t n
  *  - ag_radius_count_binned / ag_radius_fill_binned: the binning of the SOURCES (any cell size works; the
  *    search is fastest with ag_radius_cell).  Workspace: ag_radius_binned_workspace_bytes(ns, nt).
  *  - ag_knn_binned: the binning of the TARGETS (their order and unit vectors are taken from it).  Workspace:
- *    ag_knn_binned_workspace_bytes(ns, nt, k).
+ *    ag_knn_binned_workspace_bytes(ns, nt, k, src_density).
  * Results are identical to the entry points without a kept binning.  The buffer must stay untouched while
  * a search that was given it is in flight. */
 size_t ag_binning_bytes(int64_t n);
@@ -134,18 +153,18 @@ int ag_radius_count_binned(const float* d_src, int64_t ns, const void* d_src_bin
 int ag_radius_fill_binned(const float* d_src, int64_t ns, const void* d_src_binning, double src_cell, const float* d_tgt,
                           int64_t nt, double radius, const int64_t* d_offsets, int64_t num_edges, int64_t max_row,
                           int32_t* d_out_src, int32_t* d_out_tgt, void* d_ws, size_t ws_bytes, void* stream);
-size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k);
+size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k, double src_density);
 int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
-                  double tgt_cell, int k, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
-                  size_t ws_bytes, void* stream);
+                  double tgt_cell, int k, double src_density, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats,
+                  void* d_ws, size_t ws_bytes, void* stream);
 
 /* The k-NN graph as an edge list [2, nt*k] (edges/builder.py:259-265: the COO form of kneighbors_graph): d_edge_src =
  * what ag_knn writes, d_edge_tgt = the target of every entry (0,0,0,1,1,1,... for k = 3), written by the same
  * kernels instead of a pass of its own (ag_fill_row_ids).  d_tgt_binning: a binning of the targets as for
  * ag_knn_binned (workspace ag_knn_binned_workspace_bytes), or NULL (workspace ag_knn_workspace_bytes). */
 int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
-                 double tgt_cell, int k, int32_t* d_edge_src, int32_t* d_edge_tgt, int64_t* d_stats, void* d_ws,
-                 size_t ws_bytes, void* stream);
+                 double tgt_cell, int k, double src_density, double tgt_density, int32_t* d_edge_src, int32_t* d_edge_tgt,
+                 int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Icosphere nodes.

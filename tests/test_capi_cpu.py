@@ -32,11 +32,11 @@ def test_ctypes_table_matches_header():
 def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.ag_version() >= 100
-    rc = lib.ag_knn(None, 10, None, 5, 0, None, None, None, None, 0, None)
+    rc = lib.ag_knn(None, 10, None, 5, 0, 1.0, 1.0, None, None, None, None, 0, None)
     assert rc == -1 and b"k=0" in lib.ag_last_error()
-    rc = lib.ag_knn(None, 2, None, 5, 3, None, None, None, None, 0, None)
+    rc = lib.ag_knn(None, 2, None, 5, 3, 1.0, 1.0, None, None, None, None, 0, None)
     assert rc == -1 and b"exceeds" in lib.ag_last_error()
-    assert lib.ag_nn_maxdist(None, 1, None, None, 0, None) == -1
+    assert lib.ag_nn_maxdist(None, 1, 1.0, None, None, 0, None) == -1
     assert lib.ag_normalise(None, 10, 9, 0, None, 0, None) == -1
     v, f, e = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     assert lib.ag_icosphere_sizes(7, ctypes.byref(v), ctypes.byref(f), ctypes.byref(e)) == 0

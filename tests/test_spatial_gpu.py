@@ -330,3 +330,55 @@ def test_knn_within_a_bound_of_a_dense_regional_set(device, bound_km):
         np.testing.assert_allclose(dist[keep], want_d[keep], rtol=1e-12, atol=1e-15)
         differ = keep & (ids != want_i)  # (exact distance ties may list the tied sources in another order)
         np.testing.assert_allclose(dist[differ], want_d[differ], rtol=1e-12)
+
+
+def _regional(n, seed, lat0=35.0, lat1=72.0, lon0=-25.0, lon1=45.0):
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(np.sin(np.deg2rad(lat0)), np.sin(np.deg2rad(lat1)), n)
+    lon = np.deg2rad(rng.uniform(lon0, lon1, n)) % (2 * np.pi)
+    return np.stack([np.arcsin(z), lon], axis=1).astype(np.float32)
+
+
+def test_point_density_of_global_regional_and_stretched_sets(device):
+    """ag_point_density: 1 for sets spread over the sphere (random, lattice, regular grid, small), 1/f for a set
+    confined to the fraction f of the sphere, and for a stretched set the mean over its nodes."""
+    area = (np.sin(np.deg2rad(72.0)) - np.sin(np.deg2rad(35.0))) * np.deg2rad(70.0) / (4 * np.pi)
+    for x, want, tol in [(grids.random_sphere(300_000, seed=1), 1.0, 0.05), (grids.fibonacci_sphere(200_000), 1.0, 0.05),
+                         (grids.random_sphere(3_000, seed=2), 1.0, 0.3), (grids.regular(0.5), np.pi / 2, 0.1),
+                         (_regional(400_000, 3), 1.0 / area, 0.1), (_regional(5_000, 4), 1.0 / area, 0.4)]:
+        got = ops.point_density(torch.from_numpy(x).to(device))
+        assert abs(got / want - 1.0) < tol, (len(x), got, want)
+    # nine tenths of the nodes in the region, one tenth over the sphere
+    both = np.concatenate([_regional(360_000, 5), grids.random_sphere(40_000, seed=6)])
+    want = (0.9 + 0.1 * area) ** 2 / area + 0.1 ** 2 * (1 - area) / 1.0  # sum over the two parts of share^2 / area
+    got = ops.point_density(torch.from_numpy(both).to(device))
+    assert abs(got / want - 1.0) < 0.1, (got, want)
+    assert ops.point_density(torch.from_numpy(grids.random_sphere(100, seed=7)).to(device)) == 1.0
+
+
+@pytest.mark.parametrize("k", [1, 3, 12])
+def test_knn_between_regional_sets_for_any_density_given(device, k):
+    """The densities size the cells and choose the kernels; the neighbours are scikit-learn's whatever is given:
+    measured (the default), 1 (a regional set binned as if it were global), far too large, and mixed."""
+    src, tgt = _regional(60_000, 11), _regional(9_000, 12)
+    s, t = torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device)
+    rows = h.knn_rows(rp.knn_edges(src, tgt, k), len(tgt), k)
+    measured = ops.knn(s, t, k)
+    assert h.compare_knn(src, tgt, measured.cpu().numpy(), rows)["bad_rows"] == []
+    for sd, td in [(1.0, 1.0), (25.0, 1.0), (1.0, 25.0), (5_000.0, 5_000.0), (0.0, float("nan"))]:
+        assert torch.equal(ops.knn(s, t, k, src_density=sd, tgt_density=td), measured)
+        assert torch.equal(ops.knn_edges(s, t, k, src_density=sd, tgt_density=td)[0], measured.reshape(-1))
+    kept = ops.bin_points(t, 0.004)
+    for sd in (1.0, 25.0, 5_000.0):
+        assert torch.equal(ops.knn(s, None, k, tgt_binning=kept, src_density=sd), measured)
+    # the other way round (dense targets), a bounded search, and the reference distance
+    back = ops.knn(t, s, k)
+    assert h.compare_knn(tgt, src, back.cpu().numpy(), h.knn_rows(rp.knn_edges(tgt, src, k), len(src), k))["bad_rows"] == []
+    assert torch.equal(ops.knn(t, s, k, src_density=1.0, tgt_density=1.0), back)
+    world = torch.from_numpy(grids.fibonacci_sphere(20_000)).to(device)
+    for sd in (None, 1.0, 400.0):
+        ids, dist = ops.knn(s, world, k, return_dist=True, max_dist=0.02, src_density=sd, tgt_density=1.0)
+        if sd is None:
+            want_ids, want_dist = ids, dist
+        assert torch.equal(ids, want_ids) and torch.equal(dist, want_dist)
+    assert float(ops.nn_maxdist(s).item()) == float(ops.nn_maxdist(s, density=1.0).item()) == float(ops.nn_maxdist(s, density=300.0).item())

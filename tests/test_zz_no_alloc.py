@@ -18,8 +18,8 @@ def _both(lib, x: torch.Tensor):
     dev = x.device
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     want = torch.full((), -1.0, dtype=torch.float64, device=dev)
-    ws = torch.empty(max(lib.ag_nn_maxdist_workspace_bytes(n), 256), dtype=torch.uint8, device=dev)
-    _lib.check(lib.ag_nn_maxdist(x.data_ptr(), n, want.data_ptr(), ws.data_ptr(), ws.numel(), stream), "ag_nn_maxdist")
+    ws = torch.empty(max(lib.ag_nn_maxdist_workspace_bytes(n, 1.0), 256), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ag_nn_maxdist(x.data_ptr(), n, 1.0, want.data_ptr(), ws.data_ptr(), ws.numel(), stream), "ag_nn_maxdist")
     got = torch.full((), -1.0, dtype=torch.float64, device=dev)
     before = torch.cuda.memory_allocated(dev)
     _lib.check(lib.ag_nn_maxdist_static(x.data_ptr(), n, got.data_ptr(), stream), "ag_nn_maxdist_static")
