@@ -130,6 +130,23 @@ __global__ void ag_bin_scatter_kernel(const float2* __restrict__ pts, int64_t n,
   }
 }
 
+// How many points every cell of a (coarse) grid holds -- the occupancy a bounded search consults before it looks at
+// the sources themselves.  (Consecutive points mostly share a cell: the first lane of a run counts for the run.)
+__global__ void ag_occupancy_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n, int* __restrict__ count) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const float2 p = pts[i];
+    const int c = ag_cell_of(g, static_cast<double>(p.x), static_cast<double>(p.y));
+    const int lane = ag_lane();
+    const int prev = __shfl_up(c, 1, 64);
+    const bool head = (lane == 0) || (prev != c);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long active = __ballot(1);
+    const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
+    const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1) : (64 - __clzll(static_cast<long long>(active)));
+    if (head) atomicAdd(&count[c], run_end - lane);
+  }
+}
+
 int ag_grid_bands(double delta) {
   if (!(delta > 0.0)) delta = AG_PI;
   double nb = floor(AG_PI / delta);
@@ -297,6 +314,8 @@ struct AgKnnArgs {
   int per_target;            // 1: no descriptors and no binned targets -- every lane of stage 1 takes one target, in the caller's order
   const int* tcell_of;       // cell of every target, by original id
   int* range_off;            // [bands + 1] by_range: first descriptor of every band; range_off[bands] = descriptors in use
+  AgGrid occ_grid;           // bounded per-target searches: a coarse grid (cells of about the bound) ...
+  const int* occ_count;      // ... and the number of sources in each of its cells
   int bounded;               // 1: neighbours farther than rmax are not wanted (their entries become -1)
   double rmax_window;        // bounded: the widest window stage 2 scans (rmax and a rounding pad)
   double rmax_rdist;         // bounded: sin^2(rmax / 2), the acceptance threshold on the reduced distance
@@ -880,7 +899,8 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
 // with the half-width of the table: a few dozen sources) straight from the binned array.
 template <int CAP, int K>
 __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g, const int* __restrict__ sstart,
-                                                           const double rmax_window) {
+                                                           const double rmax_window, AgGrid occ,
+                                                           const int* __restrict__ occ_count) {
   const int lane = ag_lane();
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int pieces = static_cast<int>((a.nt + 63) >> 6);
@@ -942,14 +962,23 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
         }
       }
     }
-    // A search with a bound (rmax_window > 0): a target whose window is empty asks whether the latitudes within the
-    // bound hold any source at all -- the bands of the grid are contiguous in the binned array, two look-ups -- and
-    // is done if they do not (of the vertices of a global mesh looked up in a regional grid, most).
+    // A search with a bound (rmax_window > 0): a target whose window is empty consults the occupancy of a coarse
+    // grid, with cells of about the bound -- a few cells around it -- and is done if no source lies anywhere within
+    // the bound (of the vertices of a global mesh looked up in a regional grid, nearly all).
     bool settled = false;
     if (rmax_window > 0.0 && active && bi[0] < 0) {
-      const double lat = static_cast<double>(a.tgt[tid].x), pad = 1.0e-7 + 1.0e-6 * rmax_window;
-      const int b_first = ag_band_of(g, lat + rmax_window + pad), b_last = ag_band_of(g, lat - rmax_window - pad);
-      settled = sstart[g.off[b_last + 1]] == sstart[g.off[b_first]];
+      const float2 tp = a.tgt[tid];
+      const AgPointWindow pw = ag_point_window(occ, static_cast<double>(tp.x), ag_wrap_lon(static_cast<double>(tp.y)), rmax_window);
+      int near = 0;
+      for (int b = pw.b0; b <= pw.b1 && near == 0; ++b) {
+        const int nc = occ.ncols[b], base = occ.off[b];
+        for (int part = 0; part < 2; ++part) {
+          int c_first, c_last;
+          ag_window_cells(pw, nc, part != 0, &c_first, &c_last);
+          for (int c = c_first; c < c_last && near == 0; ++c) near += occ_count[base + c];
+        }
+      }
+      settled = near == 0;
       if (settled) {
         const int k = K > 0 ? K : a.k;
         for (int j = 0; j < k; ++j) {
@@ -1077,12 +1106,33 @@ __device__ __forceinline__ AgPair ag_wave_min_pair(double r, int id) {
   return {r, id};
 }
 
+// Stage 2 works on one target per wave, in windows that grow until they provably hold the k nearest.  A window can
+// hold thousands of sources (a target in the margin around a regional grid, a vertex near the rim of an area mask),
+// and ranking all of them in float64 -- k times over -- is what this path used to cost.  Now a window is first
+// looked at in float32: the candidates that can be among the k nearest are picked by their float32 chord^2
+// against a threshold found by bisection on counts, and only that set (at most AG_EXACT_SET ids, held in LDS) is
+// evaluated in float64 -- once -- and ranked from registers.
+#define AG_EXACT_SET 256
+
+// Outer threshold for an inner one: with A = {chord^2 <= t_in} and S = {chord^2 <= ag_exact_outer(t_in)} (float32
+// values), every source outside S is farther from the target, in exact arithmetic, than every member of A --
+// t_out - err(t_out) >= t_in + err(t_in) for the error bound of the float32 value.  So if A has k members, S holds
+// the k nearest.
+__device__ __forceinline__ float ag_exact_outer(float t_in) { return t_in + 4.0f * ag_chord2_err(t_in) + 1.0e-11f; }
+
 __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
+  __shared__ int set_all[4][AG_EXACT_SET];
   const int lane = ag_lane();
+  int* set = set_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
   const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int nq = *a.queue_count;
   const int k = a.k;
+  auto wave_sum = [](int v) {
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 64);
+    return v;
+  };
   // (counted per wave and added up once at the end: atomics on one word are served one after the other)
   unsigned long long stat_targets = 0, stat_rounds = 0;
   for (int q = wave_global; q < nq; q += nwaves) {
@@ -1090,34 +1140,38 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
     const float2 tpf = a.tgt[tid];
     const double tlat = tpf.x, tlon = tpf.y;
     const double tlonw = ag_wrap_lon(tlon);
-    double R = a.rg;
-    int rounds = 0;
-    if (a.bounded) {
-      // A bounded search first counts the sources of the widest window it may look at, a run per lane.  Most targets
-      // that get here have no source anywhere near (the vertices of a global mesh outside the area of the reference
-      // grid) and are done with this one look; those with few sources in reach scan that window at once instead of
-      // working up to it by doubling.
-      const AgPointWindow widest = ag_point_window(a.sgrid, tlat, tlonw, a.rmax_window);
-      const int nruns = 2 * (widest.b1 - widest.b0 + 1);
+    const float3 tu = ag_unit_vec(tpf.x, tpf.y);
+    // sources of a window, a run per lane: the dependent table look-ups of all bands are in flight together
+    auto count_window = [&](const AgPointWindow& w) {
+      const int nruns = 2 * (w.b1 - w.b0 + 1);
       int total = 0;
       for (int j = lane; j < nruns; j += 64) {
         int first, last;
-        ag_window_run(a.sgrid, a.sstart, widest, j, &first, &last);
+        ag_window_run(a.sgrid, a.sstart, w, j, &first, &last);
         total += last - first;
       }
-#pragma unroll
-      for (int ofs = 32; ofs > 0; ofs >>= 1) total += __shfl_xor(total, ofs, 64);
-      if (total == 0) {
-        if (lane == 0) {
-          for (int j = 0; j < k; ++j) {
-            a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
-            if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
-          }
+      return wave_sum(total);
+    };
+    auto write_missing = [&](int from) {
+      if (lane == 0 && !a.self_query)
+        for (int j = from; j < k; ++j) {
+          a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
+          if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
         }
+    };
+    double R = a.rg;
+    int rounds = 0;
+    if (a.bounded) {
+      // A bounded search first counts the sources of the widest window it may look at.  Most targets that get here
+      // have no source anywhere near (the vertices of a global mesh outside the area of the reference grid) and are
+      // done with this one look; those with few sources in reach scan that window at once instead of working up to it.
+      const int total = count_window(ag_point_window(a.sgrid, tlat, tlonw, a.rmax_window));
+      if (total == 0) {
+        write_missing(0);
         ++stat_targets;
         continue;
       }
-      if (total <= 1024) R = a.rmax_window;
+      if (total <= 16 * AG_EXACT_SET) R = a.rmax_window;
     }
     for (;;) {
       // a bounded search never looks farther than the bound: the pass at the bound is the last one, and what it
@@ -1126,35 +1180,96 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       if (last) R = a.rmax_window;
       const bool whole = R >= AG_PI;
       const double Rw = whole ? AG_PI : R;
-      const double s = ag_sin_f64(0.5 * Rw);
-      const double rlimit = s * s * (1.0 - 1.0e-9);
+      const double sh = ag_sin_f64(0.5 * Rw);
+      const double rlimit = sh * sh * (1.0 - 1.0e-9);
+      const AgPointWindow w = ag_point_window(a.sgrid, tlat, tlonw, Rw);
+      const int nruns = 2 * (w.b1 - w.b0 + 1);
+      const int total = count_window(w);
+      if (total < k && !last && !whole) {  // (no need to look at the sources of a window that holds fewer than k)
+        R *= 2.0;
+        ++rounds;
+        continue;
+      }
+      // f(id, chord2): every source of the window with its float32 chord^2 to the target.  All lanes make every
+      // call together (f may count with ballots): a lane without a source of its own offers an infinite chord^2.
+      auto for_each_source = [&](auto&& f) {
+        for (int j0 = 0; j0 < nruns; j0 += 64) {
+          int first_l, last_l;
+          ag_window_run(a.sgrid, a.sstart, w, j0 + lane, &first_l, &last_l);
+          const int nr = min(64, nruns - j0);
+          for (int r = 0; r < nr; ++r) {
+            const int first = __shfl(first_l, r, 64), last_p = __shfl(last_l, r, 64);
+            for (int p0 = first; p0 < last_p; p0 += 64) {
+              int id = 0x7fffffff;
+              float c = __builtin_inff();
+              if (p0 + lane < last_p) {
+                const float4 s = a.spts[p0 + lane];
+                const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
+                id = __float_as_int(s.w);
+                c = dx * dx + dy * dy + dz * dz;
+              }
+              f(id, c);
+            }
+          }
+        }
+      };
+      // ---- the float32 threshold below which the candidates are collected
+      float t_out = 3.0e38f;  // (a window that fits the set: everything)
+      int n_set = total;
+      if (total > AG_EXACT_SET) {
+        // first bracket: the k-th smallest of the lanes' own minima is the chord^2 of a k-th candidate at least
+        float lane_min = 3.0e38f;
+        for_each_source([&](int, float c) { lane_min = fminf(lane_min, c); });
+        int rank = 0;
+        for (int o = 0; o < 64; ++o) {
+          const float v = __shfl(lane_min, o, 64);
+          rank += (v < lane_min || (v == lane_min && o < lane)) ? 1 : 0;
+        }
+        const unsigned long long at = __ballot(rank == k - 1);
+        float t_hi = __shfl(lane_min, __ffsll(static_cast<long long>(at)) - 1, 64);
+        // (fewer than k lanes met a source: every source the window is sure to hold completely)
+        const float c_window = static_cast<float>(4.0 * sh * sh) * 1.000001f + 1.0e-11f;
+        if (!(t_hi < c_window)) t_hi = c_window;
+        // (below the smallest chord^2 of the window: nothing)
+        float t_lo = lane_min;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) t_lo = fminf(t_lo, __shfl_xor(t_lo, ofs, 64));
+        t_lo = t_lo * 0.999999f - 1.0e-30f;
+        auto counts = [&](float t_in, int* n_in, int* n_out) {
+          const float t_o = ag_exact_outer(t_in);
+          int ci = 0, co = 0;
+          for_each_source([&](int, float c) {
+            ci += c <= t_in ? 1 : 0;
+            co += c <= t_o ? 1 : 0;
+          });
+          *n_in = wave_sum(ci);
+          *n_out = wave_sum(co);
+        };
+        int n_in;
+        counts(t_hi, &n_in, &n_set);
+        // bisection: the inner set keeps k members (or all there are), the outer one shrinks until it fits
+        for (int it = 0; it < 24 && n_set > AG_EXACT_SET && n_in > k; ++it) {
+          const float mid = 0.5f * (t_lo + t_hi);
+          if (!(mid > t_lo && mid < t_hi)) break;
+          int m_in, m_out;
+          counts(mid, &m_in, &m_out);
+          if (m_in >= k) {
+            t_hi = mid;
+            n_in = m_in;
+            n_set = m_out;
+          } else {
+            t_lo = mid;
+          }
+        }
+        t_out = ag_exact_outer(t_hi);
+      }
       double prev_r = -1.0;
       int prev_i = -1;
       bool covered = true;
       int found = 0;
-      for (int j = 0; j < k; ++j) {
-        double best_r = 1.0e300;
-        int best_i = 0x7fffffff;
-        ag_for_each_range(a.sgrid, a.sstart, tlat, tlat, tlonw, tlonw, Rw, [&](int first, int last) {
-          for (int p = first + lane; p < last; p += 64) {
-            const int id = __float_as_int(a.spts[p].w);
-            const float2 sp = a.src[id];
-            const double r = ag_rdist(tlat, tlon, sp.x, sp.y);
-            if (ag_pair_less(prev_r, prev_i, r, id) && ag_pair_less(r, id, best_r, best_i)) {
-              best_r = r;
-              best_i = id;
-            }
-          }
-        });
-        const AgPair m = ag_wave_min_pair(best_r, best_i);
-        if (m.id == 0x7fffffff) {
-          covered = false;
-          break;
-        }
-        if (!whole && !(m.r <= rlimit)) {
-          covered = false;
-          break;
-        }
+      auto accept = [&](const AgPair& m, int j) {  // false: the window does not hold the j-th neighbour for sure
+        if (m.id == 0x7fffffff) return false;
+        if (!whole && !(m.r <= rlimit)) return false;
         prev_r = m.r;
         prev_i = m.id;
         found = j + 1;
@@ -1165,14 +1280,82 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
           a.out_src[static_cast<int64_t>(tid) * k + j] = m.id;
           if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
         }
+        return true;
+      };
+      if (n_set <= AG_EXACT_SET) {
+        // ---- the usual end: the set goes to LDS, four members per lane are evaluated in float64, once, and the k
+        // smallest are taken from the registers by k wavefront minima
+        int fill = 0;
+        for_each_source([&](int id, float c) {
+          const bool in = c <= t_out;
+          const unsigned long long m = __ballot(in);
+          if (in) set[fill + __popcll(m & ((1ull << lane) - 1ull))] = id;
+          fill += __popcll(m);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        static_assert(AG_EXACT_SET == 256, "four members per lane");
+        double r0 = 1.0e300, r1 = 1.0e300, r2 = 1.0e300, r3 = 1.0e300;
+        int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
+        auto member = [&](int slot, double* r, int* id) {
+          if (slot < fill) {
+            *id = set[slot];
+            const float2 sp = a.src[*id];
+            *r = ag_rdist(tlat, tlon, sp.x, sp.y);
+          }
+        };
+        member(lane, &r0, &i0);
+        if (fill > 64) {
+          member(lane + 64, &r1, &i1);
+          member(lane + 128, &r2, &i2);
+          member(lane + 192, &r3, &i3);
+        }
+        for (int j = 0; j < k; ++j) {
+          double best_r = 1.0e300;
+          int best_i = 0x7fffffff;
+          auto offer = [&](double r, int id) {
+            if (ag_pair_less(prev_r, prev_i, r, id) && ag_pair_less(r, id, best_r, best_i)) {
+              best_r = r;
+              best_i = id;
+            }
+          };
+          offer(r0, i0);
+          offer(r1, i1);
+          offer(r2, i2);
+          offer(r3, i3);
+          if (!accept(ag_wave_min_pair(best_r, best_i), j)) {
+            covered = false;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the set is reused by the next window)
+      } else {
+        // ---- more candidates than the set holds that float32 cannot tell apart (hundreds of sources at one
+        // distance): k passes over the window, float64 for the candidates below the threshold only
+        for (int j = 0; j < k; ++j) {
+          double best_r = 1.0e300;
+          int best_i = 0x7fffffff;
+          for_each_source([&](int id, float c) {
+            if (c <= t_out) {
+              const float2 sp = a.src[id];
+              const double r = ag_rdist(tlat, tlon, sp.x, sp.y);
+              if (ag_pair_less(prev_r, prev_i, r, id) && ag_pair_less(r, id, best_r, best_i)) {
+                best_r = r;
+                best_i = id;
+              }
+            }
+          });
+          if (!accept(ag_wave_min_pair(best_r, best_i), j)) {
+            covered = false;
+            break;
+          }
+        }
       }
       if (covered || whole) break;
       if (last) {
-        if (lane == 0 && !a.self_query)
-          for (int j = found; j < k; ++j) {
-            a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
-            if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
-          }
+        write_missing(found);
         break;
       }
       R *= 2.0;
@@ -1208,11 +1391,19 @@ static double ag_knn_delta(int64_t ns, int k) {
 // of the sphere; anything below 1, or not a number, counts as 1).
 static double ag_density(double d) { return d >= 1.0 ? d : 1.0; }
 
-// Bands of the source grid of a k-NN search: cells sized for the density of the sources where they are, but
-// never more than 32 cells per source (a set confined to a speck of the sphere would otherwise ask for a grid of
-// billions of empty cells).
-static int ag_knn_source_bands(int64_t ns, int k, double src_density) {
-  int nb = ag_grid_bands(ag_knn_delta(ns, k) / sqrt(ag_density(src_density)));
+// Bands of the source grid of a k-NN search: cells sized for the density of the sources where they are.  A grid for
+// the density d has d times the cells of a grid for as many sources spread over the sphere, all but one in d of them
+// empty, and every cell is paid for when the cell counts are scanned -- about what a lane pays for a candidate.
+// With few targets the candidates saved do not pay for the cells added: the sum of the two is smallest at
+// 3.5 sqrt(nt ns d) cells, which is the grid chosen where it is the coarser one (the area mask of a stretched mesh:
+// 2.6e6 vertices looked up in 4.6e7 grid nodes of density 10 -- 2.3 ms went into scanning 2.4e8 cells).  Never more
+// than 32 cells per source (a set confined to a speck of the sphere would otherwise ask for billions).
+static int ag_knn_source_bands(int64_t ns, int64_t nt, int k, double src_density) {
+  const double want = 2.0 * (k + 1) + 2.0;
+  double d = ag_density(src_density);
+  const double balanced = 1.1 * want * sqrt(d * static_cast<double>(nt > 0 ? nt : 1) / static_cast<double>(ns));
+  if (d > balanced) d = balanced > 1.0 ? balanced : 1.0;
+  int nb = ag_grid_bands(ag_knn_delta(ns, k) / sqrt(d));
   const double cells_max = 32.0 * static_cast<double>(ns) + 4096.0;
   const int nb_max = static_cast<int>(sqrt(cells_max * AG_PI / 4.0));  // the grid of nb bands has about 4 nb^2 / pi cells
   return nb < nb_max ? nb : (nb_max < 1 ? 1 : nb_max);
@@ -1285,6 +1476,8 @@ struct AgKnnWs {
   int* rq_count;
   struct AgWindow* windows;
   struct AgKnnArgs* args_copy;
+  int *occ_ncols, *occ_off, *occ_count;  // coarse occupancy grid of a bounded search (never finer than the source grid)
+  double* occ_win;
 };
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
@@ -1294,7 +1487,7 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   // (Source cells of half the size for targets from a kept binning -- whose boxes do not line up with the source
   // cells, so that more of a window is cells the box only touches -- were measured: fewer candidates, but more runs
   // to stage per wave, and slower in the end: O1280 decoder 0.178 -> 0.210 ms.)
-  const int nb_std = ag_knn_source_bands(ns, k, src_density);
+  const int nb_std = ag_knn_source_bands(ns, nt, k, src_density);
   const int nb = nb_std;
   const int tmult = ag_knn_tmult(nt, nb, tgt_density);
   int rc = ag_bin_points(c, d_src, ns, nb, nb, 1, true, stream, w ? &w->src : nullptr);
@@ -1334,7 +1527,15 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   AgWindow* windows = c.take<AgWindow>(win_ub);
   int* range_off = c.take<int>((nb_t > nb ? nb_t : nb) + 1);
   AgKnnArgs* args_copy = c.take<AgKnnArgs>(1);
+  int* occ_ncols = c.take<int>(nb);
+  int* occ_off = c.take<int>(nb + 1);
+  double* occ_win = c.take<double>(nb);
+  int* occ_count = c.take<int>(ag_grid_cells_ub(nb) + 1);
   if (w) {
+    w->occ_ncols = occ_ncols;
+    w->occ_off = occ_off;
+    w->occ_win = occ_win;
+    w->occ_count = occ_count;
     w->args_copy = args_copy;
     w->windows = windows;
     w->range_off = range_off;
@@ -1382,7 +1583,7 @@ static void ag_launch_stage1_k(const AgKnnArgs& a, hipStream_t stream) {
   h.rg_chord2 = a.rg_chord2;
   if (a.per_target) {
     AG_KERNEL("ag_knn_point_kernel", (ag_knn_point_kernel<CAP, K>), dim3(ag_blocks((a.nt + 63) / 64, 4, 8192)), dim3(256), stream, h, a.sgrid, a.sstart,
-              a.bounded ? a.rmax_window : 0.0);
+              a.bounded ? a.rmax_window : 0.0, a.occ_grid, a.occ_count);
   } else {
     AG_KERNEL(a.self_query ? "ag_knn_cell_kernel_self" : "ag_knn_cell_kernel", (ag_knn_cell_kernel<CAP, K>), dim3(blocks), dim3(64 * AG_WAVES_PER_BLOCK), stream, h);
   }
@@ -1470,6 +1671,29 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.max_bits = w.max_bits;
   a.stats = reinterpret_cast<long long*>(d_stats);
   a.device_copy = w.args_copy;
+  a.occ_grid = AgGrid();
+  a.occ_count = nullptr;
+  if (a.bounded && a.per_target) {
+    // occupancy of a grid with cells of about the bound (never finer than the source grid, whose cell array it is
+    // laid out like): what lets stage 1 tell a target with nothing in reach from one look at a few cells
+    int nb_occ = ag_grid_bands(a.rmax_window);
+    if (nb_occ > w.src.grid.nb) nb_occ = w.src.grid.nb;
+    a.occ_grid.nb = nb_occ;
+    a.occ_grid.dlat = AG_PI / nb_occ;
+    a.occ_grid.inv_dlat = nb_occ / AG_PI;
+    a.occ_grid.ncols = w.occ_ncols;
+    a.occ_grid.off = w.occ_off;
+    a.occ_grid.win = w.occ_win;
+    a.occ_count = w.occ_count;
+    const int64_t occ_cells = ag_grid_cells_ub(nb_occ);
+    AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(occ_cells + 1, 4096, 256)), dim3(1024), stream,
+              nb_occ, a.occ_grid.dlat, 1, w.occ_ncols, w.occ_off, w.occ_win, w.occ_count, occ_cells + 1,
+              static_cast<unsigned long long*>(nullptr), int64_t(0));
+    AG_LAUNCH_CHECK();
+    AG_KERNEL("ag_occupancy_count_kernel", ag_occupancy_count_kernel, dim3(ag_blocks(ns, 256, 16384)), dim3(256), stream,
+              a.occ_grid, a.src, ns, w.occ_count);
+    AG_LAUNCH_CHECK();
+  }
 
   // (every block of the window kernel rebuilding this table in LDS, to save the one-block kernel, was measured
   // slower: 404 blocks x a prologue of dependent loads, 31.6 -> 57.6 us per build for the two searches)
