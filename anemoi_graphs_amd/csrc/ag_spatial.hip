@@ -584,10 +584,17 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
 // windows of a search, if any): tile after tile, sorted inserts with ids.  Kept out of line, behind a call: inlined, its
 // loops and the grid it reads cost the usual path scalar registers for the whole run of the kernel.  Every value
 // read from the descriptor is the same in all lanes; `out_d` / `out_i` receive the CAP best (float32 chord^2, id).
+//
+// Where the 64 targets of a descriptor lie far apart -- the coarse background of a stretched grid, binned in cells
+// sized for its fine part: a run of 64 binned targets spans hundreds of cells -- their common window holds a thousand
+// sources of which a target's own neighbourhood holds thirty.  Every lane then scans the window of its own target
+// (`tp`, the three bands around it) straight from the binned array, as ag_knn_point_kernel does; taken when the
+// longest own window is an eighth of the common one or less (a lane's candidate costs about eight times a tile's).
 template <int CAP>
 __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* __restrict__ full,
                                                              const AgWindow* __restrict__ wp, float4* tile, float tx,
-                                                             float ty, float tz, float* out_d, int* out_i) {
+                                                             float ty, float tz, bool active, float2 tp, float* out_d,
+                                                             int* out_i) {
   const int lane = ag_lane();
   const float4* __restrict__ spts = full->spts;
   float bd[CAP];
@@ -596,6 +603,65 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
   for (int j = 0; j < CAP; ++j) {
     bd[j] = 3.0e38f;
     bi[j] = -1;
+  }
+  const int common = __builtin_amdgcn_readfirstlane(wp->total);
+  if (common > 0) {
+    const AgGrid& g = full->sgrid;
+    const int* __restrict__ sstart = full->sstart;
+    int first[6], last[6];
+    int own = 0;
+    if (active) {
+      const double lonw = ag_wrap_lon(static_cast<double>(tp.y));
+      const int band = ag_band_of(g, static_cast<double>(tp.x));
+      const double delta = g.win[band];
+      AgPointWindow pw;
+      pw.b0 = max(band - 1, 0);
+      pw.b1 = min(band + 1, g.nb - 1);
+      pw.lo = lonw - delta;
+      pw.hi = lonw + delta;
+      pw.full = delta < 0.0 || pw.hi - pw.lo >= AG_TWO_PI;
+      const int nbands = pw.b1 - pw.b0 + 1;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int b = min(pw.b0 + (j >> 1), pw.b1);
+        const int nc = g.ncols[b], base = g.off[b];
+        int c_first = 0, c_last = 0;
+        if ((j >> 1) < nbands) ag_window_cells(pw, nc, (j & 1) != 0, &c_first, &c_last);
+        const bool some = c_last > c_first;
+        first[j] = sstart[base + (some ? c_first : 0)];
+        last[j] = sstart[base + (some ? c_last : 0)];
+        own += last[j] - first[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) first[j] = last[j] = 0;
+    }
+    int longest = own;
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) longest = max(longest, __shfl_xor(longest, ofs, 64));
+    if (8 * longest <= common) {
+#pragma nounroll
+      for (int j = 0; j < 6; ++j) {
+        int p = first[0], end = last[0];
+#pragma unroll
+        for (int r = 1; r < 6; ++r)
+          if (j == r) {
+            p = first[r];
+            end = last[r];
+          }
+        for (; p < end; ++p) {
+          const float4 s = spts[p];
+          const float dx = s.x - tx, dy = s.y - ty, dz = s.z - tz;
+          ag_topk_insert<CAP>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(s.w));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CAP; ++j) {
+        out_d[j] = bd[j];
+        out_i[j] = bi[j];
+      }
+      return;
+    }
   }
   int fill = 0;
   auto scan_tile = [&](int count) {
@@ -879,7 +945,8 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
     if (!tagged) {
       float far_d[CAP];
       int far_i[CAP];
-      ag_knn_scan_general<CAP>(a.full, a.windows + wi, tile, tu.x, tu.y, tu.z, far_d, far_i);
+      ag_knn_scan_general<CAP>(a.full, a.windows + wi, tile, tu.x, tu.y, tu.z, active,
+                               active ? a.tgt[tid] : make_float2(0.f, 0.f), far_d, far_i);
 #pragma unroll
       for (int j = 0; j < CAP; ++j) {
         bd[j] = far_d[j];
