@@ -367,6 +367,21 @@ __device__ __forceinline__ int ag_order_bucket_of(float lat, int B) {
   return b < B ? b : B - 1;
 }
 
+// (lat, lon) of a vertex of the unit icosphere: cartesian_to_latlon_rad (generate/transforms.py:50-52) in float64,
+// rounded to float32 as the node builder stores it
+__device__ __forceinline__ float2 ag_vertex_latlon(const double* __restrict__ xyz, int64_t i) {
+  const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  const double lat = asin(z / (x * x + y * y + z * z));
+  const double lon = atan2(y, x);
+  return make_float2(static_cast<float>(lat), static_cast<float>(lon));
+}
+
+// the coordinates in vertex order, for the callers that order a part of the vertices themselves
+__global__ void ag_vertex_latlon_kernel(const double* __restrict__ xyz, float2* __restrict__ latlon, int64_t n) {
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    latlon[i] = ag_vertex_latlon(xyz, i);
+}
+
 __global__ void ag_order_keys_kernel(const double* __restrict__ xyz, float2* __restrict__ latlon, int64_t n,
                                      uint64_t* __restrict__ keys, int32_t* __restrict__ ids, int B,
                                      int* __restrict__ bucket_count, int* __restrict__ bucket_of,
@@ -374,10 +389,7 @@ __global__ void ag_order_keys_kernel(const double* __restrict__ xyz, float2* __r
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     float2 p;
     if (xyz != nullptr) {
-      const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-      const double lat = asin(z / (x * x + y * y + z * z));
-      const double lon = atan2(y, x);
-      p = make_float2(static_cast<float>(lat), static_cast<float>(lon));
+      p = ag_vertex_latlon(xyz, i);
       latlon[i] = p;
     } else {
       p = latlon[i];
@@ -677,7 +689,8 @@ extern "C" size_t ag_icosphere_workspace_bytes(int R) {
 extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_t* d_order, int32_t* d_rank,
                             uint64_t* d_level_edges, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(R >= 0 && R <= AG_ICO_MAX_LEVEL, "ag_icosphere: resolution %d outside [0, %d]", R, AG_ICO_MAX_LEVEL);
-  AG_REQUIRE(d_xyz && d_faces && d_latlon && d_order && d_rank && d_ws, "ag_icosphere: null pointer");
+  AG_REQUIRE(d_xyz && d_faces && d_latlon && d_ws, "ag_icosphere: null pointer");
+  AG_REQUIRE((d_order == nullptr) == (d_rank == nullptr), "ag_icosphere: d_order and d_rank go together (both, or neither)");
   if (ws_bytes < ag_icosphere_workspace_bytes(R)) return ag_fail(AG_ERR_WORKSPACE, "ag_icosphere: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AgCarver c(d_ws);
@@ -734,6 +747,12 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
   }
   const int64_t V = ag_ico_V(R);
   const int vb = ag_blocks(V, 256, 8192);
+  if (d_order == nullptr) {  // no node order wanted: the coordinates in vertex order
+    AG_KERNEL("ag_vertex_latlon_kernel", ag_vertex_latlon_kernel, dim3(vb), dim3(256), s, d_xyz,
+              reinterpret_cast<float2*>(d_latlon), V);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+  }
   AgOrderWs ow;
   ow.keys_a = w.keys_a;
   ow.keys_b = w.keys_b;

@@ -160,13 +160,17 @@ class LimitedAreaTriNodes(LimitedAreaIcosahedralNodes):
 
     def create_nodes(self):
         resolution = max(self.resolutions)
-        _xyz, _faces, latlon, order, _rank, level_edges = ops.icosphere(resolution)
-        keep = self.area_mask_builder.get_mask(latlon, density=1.0)  # in node order
-        coords = latlon[keep].contiguous()
-        node_ordering = order[keep].contiguous()
-        self.density = latlon.shape[0] / max(int(coords.shape[0]), 1)  # (the vertices of the sphere over those kept)
-        rank = torch.full((order.numel(),), -1, dtype=torch.int32, device=order.device)
-        rank[node_ordering.long()] = torch.arange(node_ordering.numel(), dtype=torch.int32, device=order.device)
+        # (the order of the whole sphere's vertices is not needed: the vertices kept are ordered among themselves,
+        # with the same comparison -- latitude, longitude, vertex id, all descending)
+        _xyz, _faces, vertices, _order, _rank, level_edges = ops.icosphere(resolution, ordered=False)
+        kept = torch.nonzero(self.area_mask_builder.get_mask(vertices, density=1.0)).squeeze(1)  # vertex ids, ascending
+        unordered = vertices[kept].contiguous()
+        among_kept = ops.node_order(unordered).long()
+        coords = unordered[among_kept].contiguous()
+        node_ordering = kept[among_kept].to(torch.int32).contiguous()
+        self.density = vertices.shape[0] / max(int(coords.shape[0]), 1)  # (the vertices of the sphere over those kept)
+        rank = torch.full((vertices.shape[0],), -1, dtype=torch.int32, device=vertices.device)
+        rank[node_ordering.long()] = torch.arange(node_ordering.numel(), dtype=torch.int32, device=vertices.device)
         mesh = IcosahedralMesh(resolution, node_ordering, rank, level_edges, (rank >= 0).to(torch.uint8))
         return _finish(mesh, coords, node_ordering)
 
@@ -196,8 +200,7 @@ class StretchedTriNodes(StretchedIcosahedronNodes):
         if self.global_resolution > lam_resolution:
             raise ValueError(f"StretchedTriNodes: the global resolution ({self.global_resolution}) must not exceed "
                              f"the resolution inside the area ({lam_resolution})")
-        _x, _f, lam_sorted, _o, lam_rank, level_edges = ops.icosphere(lam_resolution)
-        lam = lam_sorted[lam_rank.long()]  # vertex order
+        _x, _f, lam, _o, _r, level_edges = ops.icosphere(lam_resolution, ordered=False)  # vertex order
         # Refinement keeps the vertices it starts from, at the head of the vertex list: the coarse mesh is the first
         # 10 * 4**r + 2 vertices of the fine one, and one look-up of the fine vertices answers for both meshes.
         base = lam[: 10 * 4 ** self.global_resolution + 2]

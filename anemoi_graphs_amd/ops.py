@@ -452,9 +452,11 @@ def invert_ids(ids: torch.Tensor, size: int) -> torch.Tensor:
     return out
 
 
-def icosphere(resolution: int, device: torch.device | None = None):
+def icosphere(resolution: int, device: torch.device | None = None, ordered: bool = True):
     """(xyz float64 [V,3], faces int32 [F,3], latlon float32 [V,2] in node order, order int32 [V],
-    rank int32 [V], level_edges int64 [E_all] = unique mesh edges of every level 0..resolution)."""
+    rank int32 [V], level_edges int64 [E_all] = unique mesh edges of every level 0..resolution).
+    ``ordered=False``: no node order is computed -- latlon comes in vertex order, order and rank are None
+    (for the builders that keep a part of the vertices and order that part)."""
     lib = _lib.load()
     dev = device_of() if device is None else device
     v, f, e = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
@@ -465,8 +467,8 @@ def icosphere(resolution: int, device: torch.device | None = None):
         xyz = torch.empty((nv, 3), dtype=torch.float64, device=dev)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
         latlon = torch.empty((nv, 2), dtype=torch.float32, device=dev)
-        order = torch.empty(nv, dtype=torch.int32, device=dev)
-        rank = torch.empty(nv, dtype=torch.int32, device=dev)
+        order = torch.empty(nv, dtype=torch.int32, device=dev) if ordered else None
+        rank = torch.empty(nv, dtype=torch.int32, device=dev) if ordered else None
         level_edges = torch.empty(ne, dtype=torch.int64, device=dev)
         ws = _workspace(lib.ag_icosphere_workspace_bytes(resolution), dev)
         _lib.check(

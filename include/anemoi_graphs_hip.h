@@ -178,6 +178,10 @@ int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt,
  *                                (what generate/utils.py:30-32 yields with stable sorts)
  *   d_order       int32   [V]    node -> vertex  (the reference's `node_ordering`)
  *   d_rank        int32   [V]    vertex -> node  (inverse permutation)
+ *                                d_order = d_rank = NULL: no node order is computed and d_latlon receives the
+ *                                coordinates in VERTEX order -- for the limited-area and stretched meshes
+ *                                (generate/tri_icosahedron.py:47-58,61-105), which keep a part of the vertices
+ *                                and order that part (ag_node_order)
  *   d_level_edges uint64  [E_all] (nullable) the unique undirected mesh edges of every level 0..R as
  *                                (max vertex << 32 | min vertex), level l at offset 10*(4^l - 1).  This
  *                                is what the reference keeps in `_nx_graph` for MultiScaleEdges

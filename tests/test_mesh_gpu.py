@@ -188,3 +188,15 @@ def test_o96_tri5_documented_counts(device):
     assert ops.radius_edges(data, hidden, radius).shape[1] == 62980
     assert ops.multiscale_edges(5, list(range(6)), 1, rank, level_edges).shape[1] == 81900
     assert ops.knn(hidden, data, 3).numel() == 120960
+
+
+@pytest.mark.parametrize("r", [0, 2, 4, 8])
+def test_icosphere_without_a_node_order(device, r):
+    """ag_icosphere with d_order = d_rank = NULL: the same vertices, faces and level edges, the coordinates in vertex
+    order (bit for bit the ordered ones taken back to vertex order), and no order computed."""
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(r)
+    xyz2, faces2, vertices, order2, rank2, level_edges2 = ops.icosphere(r, ordered=False)
+    assert order2 is None and rank2 is None
+    assert torch.equal(xyz, xyz2) and torch.equal(faces, faces2) and torch.equal(level_edges, level_edges2)
+    assert torch.equal(vertices, latlon[rank.long()])
+    assert torch.equal(ops.node_order(vertices), order)
