@@ -1189,8 +1189,10 @@ __device__ __forceinline__ float ag_exact_outer(float t_in) { return t_in + 4.0f
 
 __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
   __shared__ int set_all[4][AG_EXACT_SET];
+  __shared__ double rdist_all[4][AG_EXACT_SET];
   const int lane = ag_lane();
   int* set = set_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+  double* set_r = rdist_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
   const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int nq = *a.queue_count;
@@ -1231,7 +1233,8 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
     if (a.bounded) {
       // A bounded search first counts the sources of the widest window it may look at.  Most targets that get here
       // have no source anywhere near (the vertices of a global mesh outside the area of the reference grid) and are
-      // done with this one look; those with few sources in reach scan that window at once instead of working up to it.
+      // done with this one look; those with up to a few thousand sources in reach take that window at once instead of
+      // working up to it (taking it at once whatever it holds was measured: no faster).
       const int total = count_window(ag_point_window(a.sgrid, tlat, tlonw, a.rmax_window));
       if (total == 0) {
         write_missing(0);
@@ -1350,8 +1353,8 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
         return true;
       };
       if (n_set <= AG_EXACT_SET) {
-        // ---- the usual end: the set goes to LDS, four members per lane are evaluated in float64, once, and the k
-        // smallest are taken from the registers by k wavefront minima
+        // ---- the usual end: the set goes to LDS, its members are evaluated in float64, once, and the k smallest
+        // are taken by k wavefront minima
         int fill = 0;
         for_each_source([&](int id, float c) {
           const bool in = c <= t_out;
@@ -1362,35 +1365,26 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        static_assert(AG_EXACT_SET == 256, "four members per lane");
-        double r0 = 1.0e300, r1 = 1.0e300, r2 = 1.0e300, r3 = 1.0e300;
-        int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
-        auto member = [&](int slot, double* r, int* id) {
-          if (slot < fill) {
-            *id = set[slot];
-            const float2 sp = a.src[*id];
-            *r = ag_rdist(tlat, tlon, sp.x, sp.y);
-          }
-        };
-        member(lane, &r0, &i0);
-        if (fill > 64) {
-          member(lane + 64, &r1, &i1);
-          member(lane + 128, &r2, &i2);
-          member(lane + 192, &r3, &i3);
+        // (one member at a time, the distances parked in LDS: four evaluations side by side took 170 registers)
+#pragma nounroll
+        for (int slot = lane; slot < fill; slot += 64) {
+          const float2 sp = a.src[set[slot]];
+          set_r[slot] = ag_rdist(tlat, tlon, sp.x, sp.y);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int j = 0; j < k; ++j) {
           double best_r = 1.0e300;
           int best_i = 0x7fffffff;
-          auto offer = [&](double r, int id) {
+          for (int slot = lane; slot < fill; slot += 64) {
+            const double r = set_r[slot];
+            const int id = set[slot];
             if (ag_pair_less(prev_r, prev_i, r, id) && ag_pair_less(r, id, best_r, best_i)) {
               best_r = r;
               best_i = id;
             }
-          };
-          offer(r0, i0);
-          offer(r1, i1);
-          offer(r2, i2);
-          offer(r3, i3);
+          }
           if (!accept(ag_wave_min_pair(best_r, best_i), j)) {
             covered = false;
             break;
