@@ -1459,10 +1459,13 @@ static double ag_density(double d) { return d >= 1.0 ? d : 1.0; }
 // 3.5 sqrt(nt ns d) cells, which is the grid chosen where it is the coarser one (the area mask of a stretched mesh:
 // 2.6e6 vertices looked up in 4.6e7 grid nodes of density 10 -- 2.3 ms went into scanning 2.4e8 cells).  Never more
 // than 32 cells per source (a set confined to a speck of the sphere would otherwise ask for billions).
-static int ag_knn_source_bands(int64_t ns, int64_t nt, int k, double src_density) {
+// `active`: the share of the targets that have sources around them at all (a search with a bound, whose other
+// targets are settled from the occupancy grid: the density of the targets over that of the sources).
+static int ag_knn_source_bands(int64_t ns, int64_t nt, int k, double src_density, double active = 1.0) {
   const double want = 2.0 * (k + 1) + 2.0;
   double d = ag_density(src_density);
-  const double balanced = 1.1 * want * sqrt(d * static_cast<double>(nt > 0 ? nt : 1) / static_cast<double>(ns));
+  const double nt_active = static_cast<double>(nt > 0 ? nt : 1) * (active < 1.0 ? active : 1.0);
+  const double balanced = 1.1 * want * sqrt(d * (nt_active > 1.0 ? nt_active : 1.0) / static_cast<double>(ns));
   if (d > balanced) d = balanced > 1.0 ? balanced : 1.0;
   int nb = ag_grid_bands(ag_knn_delta(ns, k) / sqrt(d));
   const double cells_max = 32.0 * static_cast<double>(ns) + 4096.0;
@@ -1543,12 +1546,13 @@ struct AgKnnWs {
 
 static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k,
                           bool self_query, hipStream_t stream, AgKnnWs* w, double src_density, double tgt_density,
-                          const AgKeptBinning& kept_tgt = AgKeptBinning()) {
+                          const AgKeptBinning& kept_tgt = AgKeptBinning(), bool bounded = false) {
   const bool foreign = kept_tgt.buffer != nullptr;
   // (Source cells of half the size for targets from a kept binning -- whose boxes do not line up with the source
   // cells, so that more of a window is cells the box only touches -- were measured: fewer candidates, but more runs
   // to stage per wave, and slower in the end: O1280 decoder 0.178 -> 0.210 ms.)
-  const int nb_std = ag_knn_source_bands(ns, nt, k, src_density);
+  const int nb_std = ag_knn_source_bands(ns, nt, k, src_density,
+                                         bounded ? ag_density(tgt_density) / ag_density(src_density) : 1.0);
   const int nb = nb_std;
   const int tmult = ag_knn_tmult(nt, nb, tgt_density);
   int rc = ag_bin_points(c, d_src, ns, nb, nb, 1, true, stream, w ? &w->src : nullptr);
@@ -1675,11 +1679,12 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
                       size_t ws_bytes, hipStream_t stream, double src_density, double tgt_density, double max_dist = 0.0,
                       const AgKeptBinning& kept_tgt = AgKeptBinning(), int32_t* d_out_tgt = nullptr) {
   AgCarver sizing(nullptr);
-  ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr, src_density, tgt_density, kept_tgt);
+  const bool bounded = !self_query && max_dist > 0.0 && max_dist * (1.0 + 1.0e-6) + 1.0e-9 < AG_PI;
+  ag_knn_prepare(sizing, d_src, ns, d_tgt, nt, k, self_query, stream, nullptr, src_density, tgt_density, kept_tgt, bounded);
   if (ws_bytes < sizing.total()) return ag_fail(AG_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sizing.total());
   AgCarver c(d_ws);
   AgKnnWs w;
-  int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w, src_density, tgt_density, kept_tgt);
+  int rc = ag_knn_prepare(c, d_src, ns, d_tgt, nt, k, self_query, stream, &w, src_density, tgt_density, kept_tgt, bounded);
   if (rc) return rc;
   AgKnnArgs a;
   a.sgrid = w.src.grid;
