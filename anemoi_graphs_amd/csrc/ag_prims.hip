@@ -289,9 +289,26 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
   const int64_t first = tile * (256 * ITEMS) + int64_t(tid) * ITEMS;
   long long v[ITEMS];
   long long sum = 0, mx = 0;
+  // A thread's items are 64 consecutive bytes: fetched (and stored, below) as four 16-byte pieces wherever the tile
+  // is whole and the arrays are aligned.  Item by item, every load instruction of a wave touched 64 lines for 4 bytes
+  // each, and the scan ran at the rate the L1 takes lines: 0.85 TB/s over 7e7 cell counts.
+  typedef int AgScanPiece __attribute__((ext_vector_type(4)));
+  static_assert(ITEMS * sizeof(T) == 64, "a thread's items are four 16-byte pieces");
+  const bool pieces = (tile + 1) * (256 * ITEMS) <= n &&
+                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+  if (pieces) {
+    T raw[ITEMS];
+    const AgScanPiece* src = reinterpret_cast<const AgScanPiece*>(in + first);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<AgScanPiece*>(raw + p * (ITEMS / 4)) = src[p];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) v[i] = static_cast<long long>(raw[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) v[i] = (first + i < n) ? static_cast<long long>(in[first + i]) : 0;
+  }
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
-    v[i] = (first + i < n) ? static_cast<long long>(in[first + i]) : 0;
     sum += v[i];
     mx = v[i] > mx ? v[i] : mx;
   }
@@ -355,10 +372,22 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
   }
   __syncthreads();
   long long run = s_prefix + thread_excl;
+  if (pieces) {
+    T res[ITEMS];
 #pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
-    if (first + i < n) out[first + i] = static_cast<T>(run);
-    run += v[i];
+    for (int i = 0; i < ITEMS; ++i) {
+      res[i] = static_cast<T>(run);
+      run += v[i];
+    }
+    AgScanPiece* dst = reinterpret_cast<AgScanPiece*>(out + first);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dst[p] = *reinterpret_cast<const AgScanPiece*>(res + p * (ITEMS / 4));
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (first + i < n) out[first + i] = static_cast<T>(run);
+      run += v[i];
+    }
   }
   if (tile == ntiles - 1 && tid == 255) {
     // (every predecessor has published before this tile got here, so an error any of them met is visible)
