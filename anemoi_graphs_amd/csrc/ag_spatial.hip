@@ -580,6 +580,63 @@ __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
   }
 }
 
+// The window of ONE target in the source grid -- the three bands around it, with the half-width of the band table --
+// as six runs of binned sources [first[j], last[j]) (two per band, the second one empty unless the window wraps);
+// returns the number of sources in it.  The table entries of the three bands are fetched together, then the cell
+// starts of the six runs: two waits for memory.
+__device__ __forceinline__ int ag_knn_own_window(const AgGrid& g, const int* __restrict__ sstart, float2 tp,
+                                                 int (&first)[6], int (&last)[6]) {
+  const double lonw = ag_wrap_lon(static_cast<double>(tp.y));
+  const int band = ag_band_of(g, static_cast<double>(tp.x));
+  const double delta = g.win[band];
+  AgPointWindow pw;
+  pw.b0 = max(band - 1, 0);
+  pw.b1 = min(band + 1, g.nb - 1);
+  pw.lo = lonw - delta;
+  pw.hi = lonw + delta;
+  pw.full = delta < 0.0 || pw.hi - pw.lo >= AG_TWO_PI;
+  const int nbands = pw.b1 - pw.b0 + 1;
+  int nc[3], base[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int b = min(pw.b0 + i, pw.b1);
+    nc[i] = g.ncols[b];
+    base[i] = g.off[b];
+  }
+  int total = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    int c_first = 0, c_last = 0;
+    if ((j >> 1) < nbands) ag_window_cells(pw, nc[j >> 1], (j & 1) != 0, &c_first, &c_last);
+    const bool some = c_last > c_first;
+    first[j] = sstart[base[j >> 1] + (some ? c_first : 0)];
+    last[j] = sstart[base[j >> 1] + (some ? c_last : 0)];
+    total += last[j] - first[j];
+  }
+  return total;
+}
+
+// CAP best of the six runs of a lane's own window (float32 chord^2 to the unit vector t, sorted insert with ids)
+template <int CAP>
+__device__ __forceinline__ void ag_knn_scan_own(const float4* __restrict__ spts, const int (&first)[6], const int (&last)[6],
+                                                float tx, float ty, float tz, float (&bd)[CAP], int (&bi)[CAP]) {
+#pragma nounroll
+  for (int j = 0; j < 6; ++j) {
+    int p = first[0], end = last[0];
+#pragma unroll
+    for (int r = 1; r < 6; ++r)
+      if (j == r) {
+        p = first[r];
+        end = last[r];
+      }
+    for (; p < end; ++p) {
+      const float4 s = spts[p];
+      const float dx = s.x - tx, dy = s.y - ty, dz = s.z - tz;
+      ag_topk_insert<CAP>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(s.w));
+    }
+  }
+}
+
 // Stage 1 for a window that does not fit one tile, or whose runs its descriptor does not list (a handful of
 // windows of a search, if any): tile after tile, sorted inserts with ids.  Kept out of line, behind a call: inlined, its
 // loops and the grid it reads cost the usual path scalar registers for the whole run of the kernel.  Every value
@@ -611,27 +668,7 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
     int first[6], last[6];
     int own = 0;
     if (active) {
-      const double lonw = ag_wrap_lon(static_cast<double>(tp.y));
-      const int band = ag_band_of(g, static_cast<double>(tp.x));
-      const double delta = g.win[band];
-      AgPointWindow pw;
-      pw.b0 = max(band - 1, 0);
-      pw.b1 = min(band + 1, g.nb - 1);
-      pw.lo = lonw - delta;
-      pw.hi = lonw + delta;
-      pw.full = delta < 0.0 || pw.hi - pw.lo >= AG_TWO_PI;
-      const int nbands = pw.b1 - pw.b0 + 1;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int b = min(pw.b0 + (j >> 1), pw.b1);
-        const int nc = g.ncols[b], base = g.off[b];
-        int c_first = 0, c_last = 0;
-        if ((j >> 1) < nbands) ag_window_cells(pw, nc, (j & 1) != 0, &c_first, &c_last);
-        const bool some = c_last > c_first;
-        first[j] = sstart[base + (some ? c_first : 0)];
-        last[j] = sstart[base + (some ? c_last : 0)];
-        own += last[j] - first[j];
-      }
+      own = ag_knn_own_window(g, sstart, tp, first, last);
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j) first[j] = last[j] = 0;
@@ -640,21 +677,7 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
 #pragma unroll
     for (int ofs = 32; ofs > 0; ofs >>= 1) longest = max(longest, __shfl_xor(longest, ofs, 64));
     if (8 * longest <= common) {
-#pragma nounroll
-      for (int j = 0; j < 6; ++j) {
-        int p = first[0], end = last[0];
-#pragma unroll
-        for (int r = 1; r < 6; ++r)
-          if (j == r) {
-            p = first[r];
-            end = last[r];
-          }
-        for (; p < end; ++p) {
-          const float4 s = spts[p];
-          const float dx = s.x - tx, dy = s.y - ty, dz = s.z - tz;
-          ag_topk_insert<CAP>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(s.w));
-        }
-      }
+      ag_knn_scan_own<CAP>(spts, first, last, tx, ty, tz, bd, bi);
 #pragma unroll
       for (int j = 0; j < CAP; ++j) {
         out_d[j] = bd[j];
@@ -985,49 +1008,9 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
     if (active) {
       const float2 tp = a.tgt[tid];
       const float3 tu = ag_unit_vec_f32(tp.x, tp.y);
-      const double lonw = ag_wrap_lon(static_cast<double>(tp.y));
-      const int band = ag_band_of(g, static_cast<double>(tp.x));
-      const double delta = g.win[band];
-      AgPointWindow pw;
-      pw.b0 = max(band - 1, 0);
-      pw.b1 = min(band + 1, g.nb - 1);
-      pw.lo = lonw - delta;
-      pw.hi = lonw + delta;
-      pw.full = delta < 0.0 || pw.hi - pw.lo >= AG_TWO_PI;
-      // the table entries of the three bands are fetched together, then the cell starts of the six runs (two per
-      // band, the second one empty unless the window wraps): two waits for memory before the scan
-      const int nbands = pw.b1 - pw.b0 + 1;
-      int nc[3], base[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int b = min(pw.b0 + i, pw.b1);
-        nc[i] = g.ncols[b];
-        base[i] = g.off[b];
-      }
       int first[6], last[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        int c_first = 0, c_last = 0;
-        if ((j >> 1) < nbands) ag_window_cells(pw, nc[j >> 1], (j & 1) != 0, &c_first, &c_last);
-        const bool some = c_last > c_first;
-        first[j] = sstart[base[j >> 1] + (some ? c_first : 0)];
-        last[j] = sstart[base[j >> 1] + (some ? c_last : 0)];
-      }
-#pragma nounroll
-      for (int j = 0; j < 6; ++j) {
-        int p = first[0], end = last[0];
-#pragma unroll
-        for (int r = 1; r < 6; ++r)
-          if (j == r) {
-            p = first[r];
-            end = last[r];
-          }
-        for (; p < end; ++p) {
-          const float4 s = a.spts[p];
-          const float dx = s.x - tu.x, dy = s.y - tu.y, dz = s.z - tu.z;
-          ag_topk_insert<CAP>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(s.w));
-        }
-      }
+      (void)ag_knn_own_window(g, sstart, tp, first, last);
+      ag_knn_scan_own<CAP>(a.spts, first, last, tu.x, tu.y, tu.z, bd, bi);
     }
     // A search with a bound (rmax_window > 0): a target whose window is empty consults the occupancy of a coarse
     // grid, with cells of about the bound -- a few cells around it -- and is done if no source lies anywhere within
