@@ -382,3 +382,44 @@ def test_knn_between_regional_sets_for_any_density_given(device, k):
             want_ids, want_dist = ids, dist
         assert torch.equal(ids, want_ids) and torch.equal(dist, want_dist)
     assert float(ops.nn_maxdist(s).item()) == float(ops.nn_maxdist(s, density=1.0).item()) == float(ops.nn_maxdist(s, density=300.0).item())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_knn_over_regions_of_any_size(device, seed):
+    """Sources confined to regions from a speck to half the sphere (densities from 2 to far beyond what the cell
+    arrays are allowed to follow), targets inside, around or all over the sphere, with and without a bound: the rows
+    are scikit-learn's, with the measured densities and with arbitrary ones."""
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(900 + seed)
+    ns = int(rng.choice([2_000, 30_000, 200_000]))
+    nt = int(rng.choice([500, 20_000]))
+    k = int(rng.choice([1, 2, 3, 8, 12]))
+    half = 10.0 ** rng.uniform(-2.0, 1.7)  # half-width of the region in degrees: 0.01 .. 50
+    lat_c, lon_c = rng.uniform(-80.0, 80.0), rng.uniform(0.0, 360.0)
+    lat0, lat1 = max(lat_c - half, -89.9), min(lat_c + half, 89.9)
+    src = _regional(ns, 1000 + seed, lat0, lat1, lon_c - half, lon_c + half)
+    where = rng.integers(0, 3)
+    if where == 0:
+        tgt = _regional(nt, 2000 + seed, lat0, lat1, lon_c - half, lon_c + half)
+    elif where == 1:  # a wider box around the region: many targets outside it
+        tgt = _regional(nt, 2000 + seed, max(lat_c - 3 * half, -89.9), min(lat_c + 3 * half, 89.9), lon_c - 3 * half, lon_c + 3 * half)
+    else:
+        tgt = grids.random_sphere(nt, seed=2000 + seed)
+    s, t = torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device)
+    ids, dist = ops.knn(s, t, k, return_dist=True)
+    want_d, want_i = NearestNeighbors(metric="haversine").fit(src).kneighbors(tgt, n_neighbors=k)
+    np.testing.assert_allclose(dist.cpu().numpy(), want_d, rtol=1e-12, atol=1e-15)
+    differ = ids.cpu().numpy() != want_i  # (exact distance ties may list the tied sources in another order)
+    np.testing.assert_array_equal(dist.cpu().numpy()[differ], want_d[differ])
+    for sd, td in [(1.0, 1.0), (float(10.0 ** rng.uniform(0, 6)), float(10.0 ** rng.uniform(0, 6)))]:
+        assert torch.equal(ops.knn(s, t, k, src_density=sd, tgt_density=td), ids)
+    bound = float(np.deg2rad(half) * 10.0 ** rng.uniform(-1.5, 0.5))
+    ids_b, dist_b = ops.knn(s, t, k, return_dist=True, max_dist=bound)
+    inside = want_d <= bound
+    edge = np.abs(want_d - bound) <= 1e-9 * bound
+    keep = inside & ~edge
+    got_d = dist_b.cpu().numpy()
+    np.testing.assert_allclose(got_d[keep], want_d[keep], rtol=1e-12, atol=1e-15)
+    assert np.all(np.isinf(got_d[~inside & ~edge])) and np.all(ids_b.cpu().numpy()[~inside & ~edge] == -1)
+    print("regions", seed, ns, nt, k, half, int(where), ops.point_density(s), int(inside.sum()))
