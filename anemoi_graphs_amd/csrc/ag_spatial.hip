@@ -1441,7 +1441,8 @@ static double ag_density(double d) { return d >= 1.0 ? d : 1.0; }
 // With few targets the candidates saved do not pay for the cells added: the sum of the two is smallest at
 // 3.5 sqrt(nt ns d) cells, which is the grid chosen where it is the coarser one (the area mask of a stretched mesh:
 // 2.6e6 vertices looked up in 4.6e7 grid nodes of density 10 -- 2.3 ms went into scanning 2.4e8 cells).  Never more
-// than 32 cells per source (a set confined to a speck of the sphere would otherwise ask for billions).
+// than 32 cells per source, or 2^24 for a small set (a set confined to a speck of the sphere would otherwise ask for
+// billions).
 // `active`: the share of the targets that have sources around them at all (a search with a bound, whose other
 // targets are settled from the occupancy grid: the density of the targets over that of the sources).
 static int ag_knn_source_bands(int64_t ns, int64_t nt, int k, double src_density, double active = 1.0) {
@@ -1451,7 +1452,7 @@ static int ag_knn_source_bands(int64_t ns, int64_t nt, int k, double src_density
   const double balanced = 1.1 * want * sqrt(d * (nt_active > 1.0 ? nt_active : 1.0) / static_cast<double>(ns));
   if (d > balanced) d = balanced > 1.0 ? balanced : 1.0;
   int nb = ag_grid_bands(ag_knn_delta(ns, k) / sqrt(d));
-  const double cells_max = 32.0 * static_cast<double>(ns) + 4096.0;
+  const double cells_max = fmax(32.0 * static_cast<double>(ns), 16777216.0) + 4096.0;
   const int nb_max = static_cast<int>(sqrt(cells_max * AG_PI / 4.0));  // the grid of nb bands has about 4 nb^2 / pi cells
   return nb < nb_max ? nb : (nb_max < 1 ? 1 : nb_max);
 }
@@ -1496,8 +1497,19 @@ static bool ag_knn_by_range(int tmult) { return tmult >= 1; }
 // sources); from two to three targets per cell on it loses (k = 16, 1e6 targets: 3.4 against 2.9 ms), its lanes
 // reading the same sources one by one that a wave of the cell kernel shares through its tile.
 #define AG_KNN_PER_TARGET_BELOW 1.0
-static bool ag_knn_per_target(int64_t nt, int nb, double tgt_density, bool foreign, bool same_set, bool self_query) {
-  return !foreign && !same_set && !self_query && ag_knn_targets_per_cell(nt, nb, tgt_density) < AG_KNN_PER_TARGET_BELOW;
+// Also where merged target cells would be chosen but the window of a merged cell -- its -tmult source cells, one more
+// on either side, three bands -- holds more sources than a tile: every wave would then take the tile-after-tile
+// path with its handful of targets (10^6 regional sources, 6e4 targets among them, k = 12: 14.7 ms against 1.5).
+static bool ag_knn_per_target(int64_t ns, int64_t nt, int nb, int tmult, double src_density, double tgt_density,
+                              bool foreign, bool same_set, bool self_query) {
+  if (foreign || same_set || self_query) return false;
+  if (ag_knn_targets_per_cell(nt, nb, tgt_density) < AG_KNN_PER_TARGET_BELOW) return true;
+  if (tmult < 0) {
+    const double dlat = AG_PI / nb;
+    const double sources_per_cell = static_cast<double>(ns) * ag_density(src_density) / (4.0 * AG_PI / (dlat * dlat));
+    if ((2 - tmult) * 3 * sources_per_cell > AG_TILE) return true;
+  }
+  return false;
 }
 // descriptors of a search: one per target cell, or one per range (every band ends with a partial one)
 #define AG_KNN_SELF_RANGE 40  // targets per wave when a sparse set is its own target set (about 16 source cells)
@@ -1544,7 +1556,8 @@ static int ag_knn_prepare(AgCarver& c, const float* d_src, int64_t ns, const flo
   // A set queried against itself (the reference distance, the neighbour lists of the Voronoi cells) is binned once:
   // the targets are the binned sources, taken in ranges of 64.  (The carve is the same either way.)
   const bool same_set = w != nullptr && d_src == d_tgt && ns == nt;
-  const bool per_target = ag_knn_per_target(nt, nb, tgt_density, foreign, d_src == d_tgt && ns == nt, self_query);
+  const bool per_target = ag_knn_per_target(ns, nt, nb, tmult, src_density, tgt_density, foreign,
+                                            d_src == d_tgt && ns == nt, self_query);
   int nb_t = nb;
   if (foreign) {  // the caller's binning of the targets: nothing to bin, nothing to carve
     nb_t = ag_kept_bands(nt, kept_tgt.cell);
@@ -1936,8 +1949,8 @@ extern "C" int ag_nn_maxdist_static(const float* d_pts, int64_t n, double* d_out
 #define AG_DENSITY_MAX_CELLS 32768
 
 static void ag_density_grid(int64_t n, int* rows, int* cols) {
-  int r = 8;  // rows x 2 rows cells, about 64 nodes per cell of a uniform set
-  while (2 * (2 * r) * (2 * r) <= n / 64 && 2 * (2 * r) * (2 * r) <= AG_DENSITY_MAX_CELLS) r *= 2;
+  int r = 8;  // rows x 2 rows cells, 16 to 64 nodes per cell of a uniform set
+  while (2 * (2 * r) * (2 * r) <= n / 16 && 2 * (2 * r) * (2 * r) <= AG_DENSITY_MAX_CELLS) r *= 2;
   *rows = r;
   *cols = 2 * r;
 }
