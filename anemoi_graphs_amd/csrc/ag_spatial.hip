@@ -1266,9 +1266,21 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
           }
         }
       };
-      // ---- the float32 threshold below which the candidates are collected
+      // ---- the float32 threshold below which the candidates are collected, and the set
+      // every source below t goes to the set (LDS) while it has room; returns how many there are
+      auto collect = [&](float t) {
+        int fill = 0;
+        for_each_source([&](int id, float c) {
+          const bool in = c <= t;
+          const unsigned long long m = __ballot(in);
+          const int slot = fill + __popcll(m & ((1ull << lane) - 1ull));
+          if (in && slot < AG_EXACT_SET) set[slot] = id;
+          fill += __popcll(m);
+        });
+        return fill;
+      };
       float t_out = 3.0e38f;  // (a window that fits the set: everything)
-      int n_set = total;
+      float t_lo = 0.0f, t_hi = 0.0f;
       if (total > AG_EXACT_SET) {
         // first bracket: the k-th smallest of the lanes' own minima is the chord^2 of a k-th candidate at least
         float lane_min = 3.0e38f;
@@ -1279,15 +1291,20 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
           rank += (v < lane_min || (v == lane_min && o < lane)) ? 1 : 0;
         }
         const unsigned long long at = __ballot(rank == k - 1);
-        float t_hi = __shfl(lane_min, __ffsll(static_cast<long long>(at)) - 1, 64);
+        t_hi = __shfl(lane_min, __ffsll(static_cast<long long>(at)) - 1, 64);
         // (fewer than k lanes met a source: every source the window is sure to hold completely)
         const float c_window = static_cast<float>(4.0 * sh * sh) * 1.000001f + 1.0e-11f;
         if (!(t_hi < c_window)) t_hi = c_window;
         // (below the smallest chord^2 of the window: nothing)
-        float t_lo = lane_min;
+        t_lo = lane_min;
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) t_lo = fminf(t_lo, __shfl_xor(t_lo, ofs, 64));
         t_lo = t_lo * 0.999999f - 1.0e-30f;
+        t_out = ag_exact_outer(t_hi);
+      }
+      // the set of the first bracket nearly always fits: collected at once, without counting first
+      int n_set = collect(t_out);
+      if (n_set > AG_EXACT_SET && total > AG_EXACT_SET) {
         auto counts = [&](float t_in, int* n_in, int* n_out) {
           const float t_o = ag_exact_outer(t_in);
           int ci = 0, co = 0;
@@ -1315,6 +1332,7 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
           }
         }
         t_out = ag_exact_outer(t_hi);
+        if (n_set <= AG_EXACT_SET) n_set = collect(t_out);
       }
       double prev_r = -1.0;
       int prev_i = -1;
@@ -1338,13 +1356,7 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       if (n_set <= AG_EXACT_SET) {
         // ---- the usual end: the set goes to LDS, its members are evaluated in float64, once, and the k smallest
         // are taken by k wavefront minima
-        int fill = 0;
-        for_each_source([&](int id, float c) {
-          const bool in = c <= t_out;
-          const unsigned long long m = __ballot(in);
-          if (in) set[fill + __popcll(m & ((1ull << lane) - 1ull))] = id;
-          fill += __popcll(m);
-        });
+        const int fill = n_set;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
