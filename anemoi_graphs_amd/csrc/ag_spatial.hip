@@ -1281,10 +1281,18 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
       };
       float t_out = 3.0e38f;  // (a window that fits the set: everything)
       float t_lo = 0.0f, t_hi = 0.0f;
+      int n_set = -1;
       if (total > AG_EXACT_SET) {
         // first bracket: the k-th smallest of the lanes' own minima is the chord^2 of a k-th candidate at least
-        float lane_min = 3.0e38f;
-        for_each_source([&](int, float c) { lane_min = fminf(lane_min, c); });
+        // (every lane also keeps the source of its minimum and its second smallest value: see below)
+        float lane_min = 3.0e38f, lane_second = 3.0e38f;
+        int lane_min_id = 0x7fffffff;
+        for_each_source([&](int id, float c) {
+          const bool lower = c < lane_min;
+          lane_second = lower ? lane_min : fminf(lane_second, c);
+          lane_min_id = lower ? id : lane_min_id;
+          lane_min = lower ? c : lane_min;
+        });
         int rank = 0;
         for (int o = 0; o < 64; ++o) {
           const float v = __shfl(lane_min, o, 64);
@@ -1301,9 +1309,21 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
         for (int ofs = 32; ofs > 0; ofs >>= 1) t_lo = fminf(t_lo, __shfl_xor(t_lo, ofs, 64));
         t_lo = t_lo * 0.999999f - 1.0e-30f;
         t_out = ag_exact_outer(t_hi);
+        if (k == 1) {
+          // one neighbour wanted, and one candidate only below the threshold (one lane's minimum, that lane's next
+          // value above it): that is the set -- the usual case, settled without a second pass
+          const unsigned long long near = __ballot(lane_min <= t_out);
+          if (__popcll(near) == 1) {
+            const int owner = __ffsll(static_cast<long long>(near)) - 1;
+            if (__shfl(lane_second, owner, 64) > t_out) {
+              if (lane == owner) set[0] = lane_min_id;
+              n_set = 1;
+            }
+          }
+        }
       }
       // the set of the first bracket nearly always fits: collected at once, without counting first
-      int n_set = collect(t_out);
+      if (n_set < 0) n_set = collect(t_out);
       if (n_set > AG_EXACT_SET && total > AG_EXACT_SET) {
         auto counts = [&](float t_in, int* n_in, int* n_out) {
           const float t_o = ag_exact_outer(t_in);
