@@ -50,7 +50,7 @@ def _run(cmd: list[str]) -> None:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    headers = sorted(CSRC.glob("*.hpp")) + sorted((PKG.parent / "include").glob("*.h"))
+    headers = sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + sorted((PKG.parent / "include").glob("*.h"))
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     jobs = []

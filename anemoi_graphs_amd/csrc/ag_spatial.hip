@@ -733,105 +733,6 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
   }
 }
 
-// The end of stage 1 for the target of a lane, given the CAP best candidates (float32 chord^2, ascending, with
-// their ids) of the region the lane scanned: `ti` is what the re-ranking finds the target by (its position in the
-// binned targets, or the target itself when they are not binned), `wi` the number of the wave's piece of work (it
-// selects the re-rank queue), `tagged` whether the chord^2 values lost their low mantissa bits to a tag.
-template <int CAP, int K>
-__device__ __forceinline__ void ag_knn_classify(const AgKnnHot a, const bool active, const bool tagged, const int tid,
-                                                const int ti, const int wi, const float (&bd)[CAP], const int (&bi)[CAP]) {
-  const int lane = ag_lane();
-  const int k = K > 0 ? K : a.k;
-  // Let dk be the float32 chord^2 of the k-th entry and ek its error bound.  Every candidate whose
-  // float32 value exceeds thr_hi = dk + 3 ek + 4e-12 is provably farther (in exact arithmetic)
-  // than each of the first k entries [x - err(x) >= dk + ek for x >= thr_hi], so the exact k nearest
-  // are among the entries up to the last one below thr_hi ("cluster end" c1).  The list is
-  //   final      if c1 is the k-th entry itself and the first k gaps exceed their error bounds,
-  //   re-ranked  in float64 by ag_knn_resolve_kernel if c1 lies inside the list,
-  //   queued     for stage 2 if the cluster may run past the list or the k-th entry is not provably
-  //              inside the region the tile covers.
-  constexpr bool RESOLVE = (CAP <= AG_KNN_RESOLVE_CAP);
-  float dk = 3.0e38f;
-  int ik = -1;
-#pragma unroll
-  for (int j = 0; j < CAP; ++j)
-    if (j == k - 1) {
-      dk = bd[j];
-      ik = bi[j];
-    }
-  auto err_of = [&](float c2) { return tagged ? ag_chord2_err_tagged(c2) : ag_chord2_err(c2); };
-  const float ek = err_of(dk);
-  const float thr_hi = dk + 3.0f * ek + 4.0e-12f;
-  const bool have_k = active && (ik >= 0);
-  bool queued = active && !have_k;
-  int c1 = k - 1;
-#pragma unroll
-  for (int j = 0; j < CAP; ++j)
-    if (j >= k && bd[j] <= thr_hi) c1 = j;
-  bool exact = false;
-  if (have_k) {
-    if (c1 == CAP - 1) queued = true;
-    if (dk + ek > a.rg_chord2) queued = true;
-    exact = (c1 != k - 1);
-#pragma unroll
-    for (int j = 0; j + 1 < CAP; ++j)
-      if (j + 1 < k) exact = exact || ((bd[j + 1] - bd[j]) <= (err_of(bd[j + 1]) + err_of(bd[j])));
-    if (a.self_query) exact = true;  // the value of the 2nd smallest rdist is needed anyway
-    if (!RESOLVE && exact) queued = true;
-  }
-  const bool done = have_k && !queued;
-  if (done && !exact) {
-    int32_t* o = a.out_src + static_cast<int64_t>(tid) * k;
-#pragma unroll
-    for (int j = 0; j < CAP; ++j)
-      if (j < k) o[j] = bi[j];
-    if (a.out_tgt != nullptr) {
-      int32_t* ot = a.out_tgt + static_cast<int64_t>(tid) * k;
-#pragma unroll
-      for (int j = 0; j < CAP; ++j)
-        if (j < k) ot[j] = tid;
-    }
-  }
-  if (RESOLVE) {
-    // targets whose list has to be re-ranked in float64 are appended to a queue (one atomic per
-    // wave); the candidate lists are stored by queue slot, coalesced per rank
-    const bool rec = active && done && exact;
-    const unsigned long long m = __ballot(rec);
-    if (a.self_query) {
-      // every target is re-ranked (the value of its 2nd smallest rdist is needed): slot = target
-      if (active) {
-        a.cand_n[ti] = rec ? c1 + 1 : 0;
-        a.cand_t[ti] = ti;
-        if (rec) {
-#pragma unroll
-          for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + ti] = bi[j];
-        }
-      }
-    } else if (m) {
-      int base = 0;
-      const int leader = __ffsll(static_cast<long long>(m)) - 1;
-      const int q = wi & (a.rq - 1);
-      if (lane == leader) base = atomicAdd(a.rq_count + q * AG_KNN_RQ_STRIDE, __popcll(m));
-      base = __shfl(base, leader, 64) + q * a.rq_cap;
-      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (rec && slot < a.cand_slots) {  // (a queue holds every target that can reach it: the bound only guards the store)
-        a.cand_n[slot] = c1 + 1;
-        a.cand_t[slot] = ti;
-#pragma unroll
-        for (int j = 0; j < CAP; ++j) a.cand_ids[static_cast<int64_t>(j) * a.cand_slots + slot] = bi[j];
-      }
-    }
-  }
-  const unsigned long long mq = __ballot(queued);
-  if (mq) {  // stage-2 queue: one atomic per wave
-    int base = 0;
-    const int leader = __ffsll(static_cast<long long>(mq)) - 1;
-    if (lane == leader) base = atomicAdd(a.queue_count, __popcll(mq));
-    base = __shfl(base, leader, 64);
-    if (queued) a.queue[base + __popcll(mq & ((1ull << lane) - 1ull))] = tid;
-  }
-}
-
 // K = the number of neighbours when it is one of the small values instantiated below (the comparisons with it then
 // cost nothing), 0 = read it from the arguments.
 template <int CAP, int K>
@@ -977,7 +878,7 @@ __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(Ag
       }
     }
 
-    ag_knn_classify<CAP, K>(a, active, tagged, tid, ti, wi, bd, bi);
+#include "ag_knn_classify.inc"
     if (tb + 64 >= t1) break;
   }
 }
@@ -992,12 +893,13 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
                                                            const double rmax_window, AgGrid occ,
                                                            const int* __restrict__ occ_count) {
   const int lane = ag_lane();
+  const int k = K > 0 ? K : a.k;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int pieces = static_cast<int>((a.nt + 63) >> 6);
   for (int wi = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wi < pieces; wi += nwaves) {
     const int64_t t = int64_t(wi) * 64 + lane;
-    const bool active = t < a.nt;
-    const int tid = active ? static_cast<int>(t) : -1;
+    const bool has_target = t < a.nt;
+    const int tid = has_target ? static_cast<int>(t) : -1;
     float bd[CAP];
     int bi[CAP];
 #pragma unroll
@@ -1005,7 +907,7 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
       bd[j] = 3.0e38f;
       bi[j] = -1;
     }
-    if (active) {
+    if (has_target) {
       const float2 tp = a.tgt[tid];
       const float3 tu = ag_unit_vec_f32(tp.x, tp.y);
       int first[6], last[6];
@@ -1016,7 +918,7 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
     // grid, with cells of about the bound -- a few cells around it -- and is done if no source lies anywhere within
     // the bound (of the vertices of a global mesh looked up in a regional grid, nearly all).
     bool settled = false;
-    if (rmax_window > 0.0 && active && bi[0] < 0) {
+    if (rmax_window > 0.0 && has_target && bi[0] < 0) {
       const float2 tp = a.tgt[tid];
       const AgPointWindow pw = ag_point_window(occ, static_cast<double>(tp.x), ag_wrap_lon(static_cast<double>(tp.y)), rmax_window);
       int near = 0;
@@ -1030,14 +932,17 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
       }
       settled = near == 0;
       if (settled) {
-        const int k = K > 0 ? K : a.k;
         for (int j = 0; j < k; ++j) {
           a.out_src[static_cast<int64_t>(tid) * k + j] = -1;
           if (a.out_tgt != nullptr) a.out_tgt[static_cast<int64_t>(tid) * k + j] = tid;
         }
       }
     }
-    ag_knn_classify<CAP, K>(a, active && !settled, false, tid, tid, wi, bd, bi);
+    // what the shared end of a pass works on (the targets are not binned: the re-ranking finds them by their ids)
+    const bool active = has_target && !settled;
+    const bool tagged = false;
+    const int ti = tid;
+#include "ag_knn_classify.inc"
   }
 }
 
