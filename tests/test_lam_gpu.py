@@ -203,3 +203,53 @@ def test_a_refined_mesh_starts_with_the_vertices_it_refines(device):
         coarse = coarse_sorted[coarse_rank.long()]
         assert coarse.shape[0] == 10 * 4 ** r + 2
         assert torch.equal(coarse, fine[: coarse.shape[0]])
+
+
+def test_host_and_resident_modes_build_the_same_regional_graphs(device):
+    """A regional grid inside a global one (one node set with a `cutout` mask), limited-area and stretched meshes,
+    masked cut-off encoder, masked k-NN decoder, multi-scale processor, attributes and the post-processor: the graph
+    built with host tensors (the package's default, what the reference hands back) equals, tensor for tensor, the one
+    built resident on the device -- densities measured or taken from the mesh builders either way."""
+    from anemoi_graphs_amd import settings
+    from anemoi_graphs_amd.edges import CutOffEdges, KNNEdges
+    from anemoi_graphs_amd.processors import RemoveUnconnectedNodes
+
+    def regular(lat0, lat1, lon0, lon1, step):
+        lat = np.arange(lat1, lat0 - 1e-9, -step)
+        lon = np.arange(lon0, lon1 + 1e-9, step)
+        la, lo = np.meshgrid(lat, lon, indexing="ij")
+        return torch.from_numpy(np.deg2rad(np.stack([la.ravel(), lo.ravel()], 1)).astype(np.float32))
+
+    regional, world = regular(40.0, 60.0, -10.0, 30.0, 0.2), regular(-90.0, 90.0, 0.0, 358.0, 2.0)
+    data = torch.cat([regional, world]).contiguous()
+    cutout = torch.zeros(data.shape[0], 1, dtype=torch.bool)
+    cutout[: regional.shape[0]] = True
+    attrs = {"edge_length": {"_target_": "anemoi.graphs.edges.attributes.EdgeLength", "norm": "unit-max"},
+             "edge_dirs": {"_target_": "anemoi.graphs.edges.attributes.EdgeDirection", "norm": None}}
+    built = {}
+    for resident in (True, False):
+        for mesh in ("limited area", "stretched"):
+            with settings.resident(resident):
+                g = HeteroData()
+                g["data"].x = data.to(device) if resident else data
+                g["data"].node_type = "LatLonNodes"
+                g["data"]["cutout"] = cutout.to(device) if resident else cutout
+                if mesh == "limited area":
+                    LimitedAreaTriNodes(6, "data", "hidden", mask_attr_name="cutout", margin_radius_km=100.0).update_graph(g, {})
+                else:
+                    StretchedTriNodes(3, 6, "hidden", "data", "cutout", margin_radius_km=100.0).update_graph(g, {})
+                for b in (CutOffEdges("data", "hidden", 0.6, source_mask_attr_name="cutout"),
+                          KNNEdges("hidden", "data", 3, target_mask_attr_name="cutout"), MultiScaleEdges("hidden", "hidden", 1)):
+                    b.update_graph(g)
+                    b.register_attributes(g, attrs)
+                RemoveUnconnectedNodes("data", save_mask_indices_to_attr="kept").update_graph(g)
+                tensors = {(str(k), n): v for k in [*g.node_types, *g.edge_types] for n, v in g[k].items()
+                           if isinstance(v, torch.Tensor) and not n.startswith("_")}
+                assert resident or not any(v.is_cuda for v in tensors.values())
+                built[(resident, mesh)] = {key: v.cpu() for key, v in tensors.items()}
+    for mesh in ("limited area", "stretched"):
+        on_device, on_host = built[(True, mesh)], built[(False, mesh)]
+        assert on_device.keys() == on_host.keys() and len(on_device) >= 13
+        for key in on_device:
+            assert torch.equal(on_device[key], on_host[key]), (mesh, key)
+        assert on_host[("data", "x")].shape[0] == regional.shape[0]  # (the global nodes have no edges and are dropped)
