@@ -1369,8 +1369,8 @@ static double ag_knn_delta(int64_t ns, int k) {
 
 // A density as the callers state it: how many times more nodes per steradian the set has, where it has nodes, than
 // the same number of nodes spread over the whole sphere (1 for a global set, 1/f for one that covers the fraction f
-// of the sphere; anything below 1, or not a number, counts as 1).
-static double ag_density(double d) { return d >= 1.0 ? d : 1.0; }
+// of the sphere; anything below 1, or not a number, counts as 1, anything beyond 1e12 as that).
+static double ag_density(double d) { return d >= 1.0 ? (d < 1.0e12 ? d : 1.0e12) : 1.0; }
 
 // Bands of the source grid of a k-NN search: cells sized for the density of the sources where they are.  A grid for
 // the density d has d times the cells of a grid for as many sources spread over the sphere, all but one in d of them

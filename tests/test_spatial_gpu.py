@@ -365,7 +365,7 @@ def test_knn_between_regional_sets_for_any_density_given(device, k):
     rows = h.knn_rows(rp.knn_edges(src, tgt, k), len(tgt), k)
     measured = ops.knn(s, t, k)
     assert h.compare_knn(src, tgt, measured.cpu().numpy(), rows)["bad_rows"] == []
-    for sd, td in [(1.0, 1.0), (25.0, 1.0), (1.0, 25.0), (5_000.0, 5_000.0), (0.0, float("nan"))]:
+    for sd, td in [(1.0, 1.0), (25.0, 1.0), (1.0, 25.0), (5_000.0, 5_000.0), (0.0, float("nan")), (float("inf"), 1e300)]:
         assert torch.equal(ops.knn(s, t, k, src_density=sd, tgt_density=td), measured)
         assert torch.equal(ops.knn_edges(s, t, k, src_density=sd, tgt_density=td)[0], measured.reshape(-1))
     kept = ops.bin_points(t, 0.004)
