@@ -240,3 +240,19 @@ def test_graph_descriptor_summaries(tmp_path, capsys):
     GraphDescriptor(tmp_path / "g.pt").describe()
     out = capsys.readouterr().out
     assert "Isolated Source" in out and "Graph ready." in out
+
+
+def test_stores_of_the_stand_in_container_can_be_deleted():
+    """`del graph[key]`, as torch_geometric's HeteroData allows it (a recipe step may replace an edge set)."""
+    from anemoi_graphs_amd import hetero
+
+    if hetero.HAVE_TORCH_GEOMETRIC:
+        pytest.skip("torch_geometric's own container is in use")
+    graph = HeteroData()
+    graph["a"].x = torch.zeros(3, 2)
+    graph[("a", "to", "a")].edge_index = torch.zeros((2, 0), dtype=torch.int32)
+    assert graph.edge_types == [("a", "to", "a")]
+    del graph[["a", "to", "a"]]
+    assert graph.edge_types == [] and graph.node_types == ["a"] and ("a", "to", "a") not in graph
+    with pytest.raises(KeyError):
+        del graph[("a", "to", "a")]
