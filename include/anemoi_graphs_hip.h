@@ -141,7 +141,8 @@ int ag_radius_fill(const float* d_src, int64_t ns, const float* d_tgt, int64_t n
  *  - ag_radius_count_binned / ag_radius_fill_binned: the binning of the SOURCES (any cell size works; the
  *    search is fastest with ag_radius_cell).  Workspace: ag_radius_binned_workspace_bytes(ns, nt).
  *  - ag_knn_binned: the binning of the TARGETS (their order and unit vectors are taken from it).  Workspace:
- *    ag_knn_binned_workspace_bytes(ns, nt, k, src_density).
+ *    ag_knn_binned_workspace_bytes(ns, nt, k, src_density).  src_density: of the sources, as for ag_knn (the binning
+ *    says where the targets are; their density is not asked for).
  * Results are identical to the entry points without a kept binning.  The buffer must stay untouched while
  * a search that was given it is in flight. */
 size_t ag_binning_bytes(int64_t n);
@@ -161,7 +162,8 @@ int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt
 /* The k-NN graph as an edge list [2, nt*k] (edges/builder.py:259-265: the COO form of kneighbors_graph): d_edge_src =
  * what ag_knn writes, d_edge_tgt = the target of every entry (0,0,0,1,1,1,... for k = 3), written by the same
  * kernels instead of a pass of its own (ag_fill_row_ids).  d_tgt_binning: a binning of the targets as for
- * ag_knn_binned (workspace ag_knn_binned_workspace_bytes), or NULL (workspace ag_knn_workspace_bytes). */
+ * ag_knn_binned (workspace ag_knn_binned_workspace_bytes), or NULL (workspace ag_knn_workspace_bytes).  src_density,
+ * tgt_density: as for ag_knn (tgt_density is not read when a binning of the targets is given). */
 int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
                  double tgt_cell, int k, double src_density, double tgt_density, int32_t* d_edge_src, int32_t* d_edge_tgt,
                  int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream);
