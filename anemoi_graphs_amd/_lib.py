@@ -72,6 +72,8 @@ SIGNATURES = {
     "ag_mask_compact": (c_int, [_P, c_int64, _P, _P, _P, c_size_t, _P]),
     "ag_gather_coords": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P]),
     "ag_remap_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
+    "ag_mesh_maxdist_workspace_bytes": (c_size_t, [c_int]),
+    "ag_mesh_maxdist": (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "ag_node_order_workspace_bytes": (c_size_t, [c_int64]),
     "ag_node_order": (c_int, [_P, c_int64, _P, _P, c_size_t, _P]),
     "ag_mark_ids": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),

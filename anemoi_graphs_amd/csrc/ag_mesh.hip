@@ -768,6 +768,96 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
 }
 
 // ---------------------------------------------------------------------------------------------
+// reference distance of the complete icosphere, from its mesh
+// ---------------------------------------------------------------------------------------------
+// The triangulation of a refined icosahedron is a Delaunay triangulation of its vertices (every triangle is close to
+// equilateral: the two angles opposite an edge add up to far less than 180 degrees), and the nearest neighbour of a
+// point is always one of its Delaunay neighbours.  So the distance from a node to its nearest other node is the
+// length of its shortest mesh edge, and the grid reference distance -- the largest such distance -- needs no search:
+// one pass over the edges of the finest level (the reduced distance scikit-learn ranks by, from the float32
+// coordinates of the nodes, evaluated from either end as a query from that end would), a minimum per vertex, the
+// maximum of the minima.
+__global__ void ag_mesh_maxdist_clear_kernel(unsigned long long* __restrict__ vertex_min, int64_t V,
+                                             unsigned long long* __restrict__ max_bits) {
+  for (int64_t v = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; v < V; v += int64_t(gridDim.x) * blockDim.x)
+    vertex_min[v] = 0x7ff0000000000000ull;  // +infinity
+  if (blockIdx.x == 0 && threadIdx.x == 0) *max_bits = 0ull;
+}
+
+__global__ void ag_mesh_maxdist_edges_kernel(const uint64_t* __restrict__ edges, int64_t E, const float2* __restrict__ latlon,
+                                             const int32_t* __restrict__ rank, int64_t V,
+                                             unsigned long long* __restrict__ vertex_min) {
+  for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < E; e += int64_t(gridDim.x) * blockDim.x) {
+    const uint64_t key = edges[e];
+    const int64_t a = static_cast<int64_t>(key & 0xffffffffull), b = static_cast<int64_t>(key >> 32);
+    if (a >= V || b >= V || a == b) continue;  // (not an edge of this mesh)
+    const int ra = rank[a], rb = rank[b];
+    if (ra < 0 || ra >= V || rb < 0 || rb >= V) continue;
+    const float2 pa = latlon[ra], pb = latlon[rb];
+    // (positive float64 values order like their bit patterns)
+    const double from_a = ag_rdist(pa.x, pa.y, pb.x, pb.y), from_b = ag_rdist(pb.x, pb.y, pa.x, pa.y);
+    atomicMin(vertex_min + a, static_cast<unsigned long long>(__double_as_longlong(from_a)));
+    atomicMin(vertex_min + b, static_cast<unsigned long long>(__double_as_longlong(from_b)));
+  }
+}
+
+__global__ __launch_bounds__(256) void ag_mesh_maxdist_max_kernel(const unsigned long long* __restrict__ vertex_min, int64_t V,
+                                                                  unsigned long long* __restrict__ max_bits) {
+  __shared__ unsigned long long partial[4];
+  unsigned long long best = 0ull;
+  for (int64_t v = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; v < V; v += int64_t(gridDim.x) * blockDim.x) {
+    const unsigned long long m = vertex_min[v];
+    // as dists[dists > 0].max() of the reference: a vertex without a positive distance does not count
+    if (m != 0x7ff0000000000000ull && m != 0ull) best = m > best ? m : best;
+  }
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    const unsigned long long other = __shfl_xor(best, ofs, 64);
+    best = other > best ? other : best;
+  }
+  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) best = partial[w] > best ? partial[w] : best;
+    if (best) atomicMax(max_bits, best);
+  }
+}
+
+__global__ void ag_mesh_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
+  const double r = __longlong_as_double(static_cast<long long>(*max_bits));
+  *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
+}
+
+extern "C" size_t ag_mesh_maxdist_workspace_bytes(int R) {
+  if (R < 0 || R > AG_ICO_MAX_LEVEL) return 0;
+  return sizeof(unsigned long long) * (ag_ico_V(R) + 1) + 512;
+}
+
+extern "C" int ag_mesh_maxdist(int R, const uint64_t* d_level_edges, const float* d_latlon, const int32_t* d_rank,
+                               double* d_out_max, void* d_ws, size_t ws_bytes, void* stream) {
+  AG_REQUIRE(R >= 0 && R <= AG_ICO_MAX_LEVEL, "ag_mesh_maxdist: resolution %d outside [0, %d]", R, AG_ICO_MAX_LEVEL);
+  AG_REQUIRE(d_level_edges && d_latlon && d_rank && d_out_max && d_ws, "ag_mesh_maxdist: null pointer");
+  if (ws_bytes < ag_mesh_maxdist_workspace_bytes(R)) return ag_fail(AG_ERR_WORKSPACE, "ag_mesh_maxdist: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t V = ag_ico_V(R), E = ag_ico_E(R);
+  AgCarver c(d_ws);
+  unsigned long long* vertex_min = c.take<unsigned long long>(V);
+  unsigned long long* max_bits = c.take<unsigned long long>(1);
+  AG_KERNEL("ag_mesh_maxdist_clear_kernel", ag_mesh_maxdist_clear_kernel, dim3(ag_blocks(V, 256, 4096)), dim3(256), s, vertex_min, V,
+            max_bits);
+  AG_LAUNCH_CHECK();
+  AG_KERNEL("ag_mesh_maxdist_edges_kernel", ag_mesh_maxdist_edges_kernel, dim3(ag_blocks(E, 256, 8192)), dim3(256), s,
+            d_level_edges + ag_ico_edge_offset(R), E, reinterpret_cast<const float2*>(d_latlon), d_rank, V, vertex_min);
+  AG_LAUNCH_CHECK();
+  AG_KERNEL("ag_mesh_maxdist_max_kernel", ag_mesh_maxdist_max_kernel, dim3(ag_blocks(V, 256, 1024)), dim3(256), s, vertex_min, V,
+            max_bits);
+  AG_LAUNCH_CHECK();
+  AG_KERNEL("ag_mesh_maxdist_finish_kernel", ag_mesh_maxdist_finish_kernel, dim3(1), dim3(1), s, max_bits, d_out_max);
+  AG_LAUNCH_CHECK();
+  return AG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // multi-scale edges
 // ---------------------------------------------------------------------------------------------
 static inline int ag_hops_capacity(int x_hops) { return 3 * x_hops * (x_hops + 1); }

@@ -39,8 +39,12 @@ def _global_sources(backend) -> dict:
     return {"src_density": 1.0} if backend is _hip_ops else {}
 
 
-def _global_set(backend) -> dict:
-    return {"density": 1.0} if backend is _hip_ops else {}
+def _reference_distance(backend, resolution: int, hidden, rank_map, level_edges):
+    """Grid reference distance of the complete hidden mesh: from its mesh edges with the HIP backend (the nearest
+    neighbour of a vertex of the icosphere is a mesh neighbour), by the search of any other backend."""
+    if backend is _hip_ops:
+        return backend.mesh_maxdist(resolution, level_edges, hidden, rank_map)
+    return backend.nn_maxdist(hidden)
 from . import settings
 from .hetero import HeteroData
 
@@ -360,7 +364,7 @@ class ShardedGraphBuilder:
 
         # ---- encoder: hidden targets of my band, data sources = my band + halo
         # (band limits by binary search on the device; one host synchronisation for all of them)
-        radius_t = be.nn_maxdist(hidden, **_global_set(be)).to(dev).double() * self.cutoff_factor
+        radius_t = _reference_distance(be, self.resolution, hidden, rank_map, level_edges).to(dev).double() * self.cutoff_factor
         reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
         nd = self.data_local.shape[0]
         neg_hlat = (-hidden[:, 0]).contiguous()
@@ -628,7 +632,7 @@ class BandGraphBuilder:
                 self._processor_edges(graph, proc_name, hidden, rank_map, level_edges, mark)
 
         # ---- sources of the encoder: my band plus the rows my neighbours send
-        radius_t = be.nn_maxdist(hidden, **_global_set(be)).to(dev).double() * self.cutoff_factor
+        radius_t = _reference_distance(be, self.resolution, hidden, rank_map, level_edges).to(dev).double() * self.cutoff_factor
         reach_t = radius_t * (1.0 + 1.0e-6) + 1.0e-6  # (the pad also covers the float32 rounding of the search keys)
         neg_hlat = (-hidden[:, 0]).contiguous()
         zero = torch.zeros((), dtype=torch.int64, device=dev)

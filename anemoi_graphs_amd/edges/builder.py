@@ -205,7 +205,16 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
         kept = target_nodes["_reference_distance"] if "_reference_distance" in target_nodes else None
         if mask is None and isinstance(kept, tuple) and kept[0] == key:
             return kept[1] * self.cutoff_factor
-        target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask, density=node_density(target_nodes))
+        mesh = target_nodes["_nx_graph"] if "_nx_graph" in target_nodes else None
+        node_type = target_nodes["node_type"] if "node_type" in target_nodes else None
+        if (node_type == "TriNodes" and mesh is not None and getattr(mesh, "active", True) is None
+                and int(target_nodes.x.shape[0]) == 10 * 4 ** mesh.resolution + 2 and mask is None):
+            # the complete icosphere: the nearest neighbour of a vertex is a mesh neighbour, no search is needed
+            target_grid_reference_distance = float(
+                ops.mesh_maxdist(mesh.resolution, mesh.level_edges, target_nodes.x, mesh.rank).item())
+        else:
+            target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask,
+                                                                         density=node_density(target_nodes))
         if mask is None:
             target_nodes["_reference_distance"] = (key, target_grid_reference_distance)
         return target_grid_reference_distance * self.cutoff_factor

@@ -479,6 +479,21 @@ def icosphere(resolution: int, device: torch.device | None = None, ordered: bool
     return xyz, faces, latlon, order, rank, level_edges
 
 
+def mesh_maxdist(resolution: int, level_edges: torch.Tensor, latlon: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
+    """0-dim float64 device tensor: the grid reference distance of the COMPLETE icosphere of this resolution -- what
+    ``nn_maxdist(latlon)`` finds by a search -- from its mesh edges (``ag_mesh_maxdist``).  ``level_edges``, ``latlon``
+    (node order) and ``rank`` as ``icosphere(resolution)`` returns them."""
+    lib = _lib.load()
+    dev = level_edges.device
+    latlon = coords(latlon, dev)
+    with _on(dev):
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        ws = _workspace(lib.ag_mesh_maxdist_workspace_bytes(resolution), dev)
+        _lib.check(lib.ag_mesh_maxdist(resolution, _ptr(level_edges), _ptr(latlon), _ptr(rank), _ptr(out), _ptr(ws),
+                                       ws.numel(), _stream(dev)), "ag_mesh_maxdist")
+    return out
+
+
 def node_order(latlon: torch.Tensor) -> torch.Tensor:
     """int32 [N] permutation that orders nodes by latitude descending (ties: longitude descending,
     then id descending)."""

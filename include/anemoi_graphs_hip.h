@@ -195,6 +195,16 @@ size_t ag_icosphere_workspace_bytes(int R);
 int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_t* d_order, int32_t* d_rank,
                  uint64_t* d_level_edges, void* d_ws, size_t ws_bytes, void* stream);
 
+/* The grid reference distance (utils.py:61-63, what ag_nn_maxdist computes by a search) of the COMPLETE icosphere of
+ * level R, from its mesh: the triangulation is a Delaunay triangulation of its vertices, the nearest neighbour of a
+ * vertex is therefore a mesh neighbour, and the largest nearest-neighbour distance is the maximum over the vertices
+ * of their shortest finest-level edge.  Same float64 result as ag_nn_maxdist on d_latlon, bit for bit, in four small
+ * launches.  d_level_edges, d_latlon (node order), d_rank: as ag_icosphere returns them for the same R.  Not for
+ * meshes that keep a part of the vertices (a node at the rim may have lost its nearest neighbour). */
+size_t ag_mesh_maxdist_workspace_bytes(int R);
+int ag_mesh_maxdist(int R, const uint64_t* d_level_edges, const float* d_latlon, const int32_t* d_rank, double* d_out_max,
+                    void* d_ws, size_t ws_bytes, void* stream);
+
 /* Node order of a set of (lat, lon) float32 coordinates: latitude descending, ties longitude
  * descending, ties node id descending -- what get_coordinates_ordering (generate/utils.py:15-33)
  * yields when its two argsorts are stable.  d_order[i] = id of the node at position i. */

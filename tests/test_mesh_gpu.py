@@ -200,3 +200,28 @@ def test_icosphere_without_a_node_order(device, r):
     assert torch.equal(xyz, xyz2) and torch.equal(faces, faces2) and torch.equal(level_edges, level_edges2)
     assert torch.equal(vertices, latlon[rank.long()])
     assert torch.equal(ops.node_order(vertices), order)
+
+
+@pytest.mark.parametrize("r", [0, 1, 2, 3, 5, 7, 9])
+def test_reference_distance_of_the_icosphere_from_its_mesh(device, r):
+    """ag_mesh_maxdist == ag_nn_maxdist on the nodes of the complete icosphere, bit for bit (the nearest neighbour of a
+    vertex is a mesh neighbour), and the cut-off builder takes it for TriNodes targets."""
+    _xyz, _faces, latlon, _order, rank, level_edges = ops.icosphere(r)
+    want = float(ops.nn_maxdist(latlon, density=1.0).item())
+    got = float(ops.mesh_maxdist(r, level_edges, latlon, rank).item())
+    assert got == want and got > 0.0
+    if r in (3, 5):
+        from anemoi_graphs_amd import settings
+        from anemoi_graphs_amd.edges import CutOffEdges
+        from anemoi_graphs_amd.hetero import HeteroData
+        from anemoi_graphs_amd.nodes import TriNodes
+
+        for resident in (True, False):
+            with settings.resident(resident):
+                graph = HeteroData()
+                graph = TriNodes(r, "hidden").update_graph(graph, {})
+                assert CutOffEdges("hidden", "hidden", 0.6).get_cutoff_radius(graph) == 0.6 * want
+                # nodes that are no longer the complete mesh: the search again
+                graph["hidden"].x = graph["hidden"].x[:-1].clone()
+                part = float(ops.nn_maxdist(graph["hidden"].x).item())
+                assert CutOffEdges("hidden", "hidden", 0.6).get_cutoff_radius(graph) == 0.6 * part
