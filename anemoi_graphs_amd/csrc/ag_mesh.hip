@@ -775,13 +775,14 @@ extern "C" int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_lat
 // point is always one of its Delaunay neighbours.  So the distance from a node to its nearest other node is the
 // length of its shortest mesh edge, and the grid reference distance -- the largest such distance -- needs no search:
 // one pass over the edges of the finest level (the reduced distance scikit-learn ranks by, from the float32
-// coordinates of the nodes, evaluated from either end as a query from that end would), a minimum per vertex, the
-// maximum of the minima.
+// coordinates of the nodes -- the same bits from either end: the sine used is an odd function bit for bit, its
+// squares do not see the order of the two nodes, and the product of the two cosines commutes), a minimum per vertex,
+// the maximum of the minima.
 __global__ void ag_mesh_maxdist_clear_kernel(unsigned long long* __restrict__ vertex_min, int64_t V,
                                              unsigned long long* __restrict__ max_bits) {
   for (int64_t v = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; v < V; v += int64_t(gridDim.x) * blockDim.x)
     vertex_min[v] = 0x7ff0000000000000ull;  // +infinity
-  if (blockIdx.x == 0 && threadIdx.x == 0) *max_bits = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) max_bits[0] = max_bits[1] = 0ull;  // the maximum, the blocks done
 }
 
 __global__ void ag_mesh_maxdist_edges_kernel(const uint64_t* __restrict__ edges, int64_t E, const float2* __restrict__ latlon,
@@ -795,14 +796,17 @@ __global__ void ag_mesh_maxdist_edges_kernel(const uint64_t* __restrict__ edges,
     if (ra < 0 || ra >= V || rb < 0 || rb >= V) continue;
     const float2 pa = latlon[ra], pb = latlon[rb];
     // (positive float64 values order like their bit patterns)
-    const double from_a = ag_rdist(pa.x, pa.y, pb.x, pb.y), from_b = ag_rdist(pb.x, pb.y, pa.x, pa.y);
-    atomicMin(vertex_min + a, static_cast<unsigned long long>(__double_as_longlong(from_a)));
-    atomicMin(vertex_min + b, static_cast<unsigned long long>(__double_as_longlong(from_b)));
+    const unsigned long long r = static_cast<unsigned long long>(__double_as_longlong(ag_rdist(pa.x, pa.y, pb.x, pb.y)));
+    atomicMin(vertex_min + a, r);
+    atomicMin(vertex_min + b, r);
   }
 }
 
+// (the block that finishes last turns the maximum into the distance: the blocks are few, so their counting in costs
+// less than a launch)
 __global__ __launch_bounds__(256) void ag_mesh_maxdist_max_kernel(const unsigned long long* __restrict__ vertex_min, int64_t V,
-                                                                  unsigned long long* __restrict__ max_bits) {
+                                                                  unsigned long long* __restrict__ max_bits,
+                                                                  double* __restrict__ out) {
   __shared__ unsigned long long partial[4];
   unsigned long long best = 0ull;
   for (int64_t v = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; v < V; v += int64_t(gridDim.x) * blockDim.x) {
@@ -820,17 +824,17 @@ __global__ __launch_bounds__(256) void ag_mesh_maxdist_max_kernel(const unsigned
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w) best = partial[w] > best ? partial[w] : best;
     if (best) atomicMax(max_bits, best);
+    __threadfence();
+    if (atomicAdd(max_bits + 1, 1ull) == gridDim.x - 1) {
+      const double r = __longlong_as_double(static_cast<long long>(atomicMax(max_bits, 0ull)));
+      *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
+    }
   }
-}
-
-__global__ void ag_mesh_maxdist_finish_kernel(const unsigned long long* max_bits, double* out) {
-  const double r = __longlong_as_double(static_cast<long long>(*max_bits));
-  *out = (r > 0.0) ? ag_rdist_to_dist(r) : 0.0;
 }
 
 extern "C" size_t ag_mesh_maxdist_workspace_bytes(int R) {
   if (R < 0 || R > AG_ICO_MAX_LEVEL) return 0;
-  return sizeof(unsigned long long) * (ag_ico_V(R) + 1) + 512;
+  return sizeof(unsigned long long) * (ag_ico_V(R) + 2) + 512;
 }
 
 extern "C" int ag_mesh_maxdist(int R, const uint64_t* d_level_edges, const float* d_latlon, const int32_t* d_rank,
@@ -842,17 +846,15 @@ extern "C" int ag_mesh_maxdist(int R, const uint64_t* d_level_edges, const float
   const int64_t V = ag_ico_V(R), E = ag_ico_E(R);
   AgCarver c(d_ws);
   unsigned long long* vertex_min = c.take<unsigned long long>(V);
-  unsigned long long* max_bits = c.take<unsigned long long>(1);
+  unsigned long long* max_bits = c.take<unsigned long long>(2);
   AG_KERNEL("ag_mesh_maxdist_clear_kernel", ag_mesh_maxdist_clear_kernel, dim3(ag_blocks(V, 256, 4096)), dim3(256), s, vertex_min, V,
             max_bits);
   AG_LAUNCH_CHECK();
   AG_KERNEL("ag_mesh_maxdist_edges_kernel", ag_mesh_maxdist_edges_kernel, dim3(ag_blocks(E, 256, 8192)), dim3(256), s,
             d_level_edges + ag_ico_edge_offset(R), E, reinterpret_cast<const float2*>(d_latlon), d_rank, V, vertex_min);
   AG_LAUNCH_CHECK();
-  AG_KERNEL("ag_mesh_maxdist_max_kernel", ag_mesh_maxdist_max_kernel, dim3(ag_blocks(V, 256, 1024)), dim3(256), s, vertex_min, V,
-            max_bits);
-  AG_LAUNCH_CHECK();
-  AG_KERNEL("ag_mesh_maxdist_finish_kernel", ag_mesh_maxdist_finish_kernel, dim3(1), dim3(1), s, max_bits, d_out_max);
+  AG_KERNEL("ag_mesh_maxdist_max_kernel", ag_mesh_maxdist_max_kernel, dim3(ag_blocks(V, 1024, 64)), dim3(256), s, vertex_min, V,
+            max_bits, d_out_max);
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

@@ -198,7 +198,7 @@ int ag_icosphere(int R, double* d_xyz, int32_t* d_faces, float* d_latlon, int32_
 /* The grid reference distance (utils.py:61-63, what ag_nn_maxdist computes by a search) of the COMPLETE icosphere of
  * level R, from its mesh: the triangulation is a Delaunay triangulation of its vertices, the nearest neighbour of a
  * vertex is therefore a mesh neighbour, and the largest nearest-neighbour distance is the maximum over the vertices
- * of their shortest finest-level edge.  Same float64 result as ag_nn_maxdist on d_latlon, bit for bit, in four small
+ * of their shortest finest-level edge.  Same float64 result as ag_nn_maxdist on d_latlon, bit for bit, in three small
  * launches.  d_level_edges, d_latlon (node order), d_rank: as ag_icosphere returns them for the same R.  Not for
  * meshes that keep a part of the vertices (a node at the rim may have lost its nearest neighbour). */
 size_t ag_mesh_maxdist_workspace_bytes(int R);
