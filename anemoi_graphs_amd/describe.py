@@ -29,12 +29,13 @@ def _table(rows: list[list], header: list[str]) -> str:
 class GraphDescriptor:
     """``GraphDescriptor(path_or_graph).describe()`` (describe.py:24-26, 156-225)."""
 
-    def __init__(self, path: str | Path | HeteroData, **kwargs):
+    def __init__(self, path: str | Path | HeteroData, trusted: bool = False, **kwargs):
         if isinstance(path, (str, Path)):
             self.path = path
             from .hetero import load_graph
 
-            self.graph = load_graph(path)
+            # (a pickled graph file is only read when the caller vouches for it: see hetero.load_graph)
+            self.graph = load_graph(path, trusted=trusted)
         else:
             self.path = None
             self.graph = path

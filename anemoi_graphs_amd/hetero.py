@@ -146,16 +146,21 @@ def save_graph(graph, path) -> None:
     torch.save(graph if HAVE_TORCH_GEOMETRIC else to_portable(graph), path)
 
 
-def load_graph(path):
-    """Read a graph file: the portable form (nothing in the file is executed), else a pickled HeteroData."""
+def load_graph(path, trusted: bool = False):
+    """Read a graph file.  The portable form is read with a loader that executes nothing from the file.  A pickled
+    container object (the reference's format, ``torch.save(HeteroData)``) can only be read by running its pickle,
+    as torch_geometric's own users do for graph.pt: that happens only when the caller says the file comes from a
+    source it trusts (``trusted=True``); otherwise such a file is refused."""
     import pickle
 
     import torch
 
     try:
         content = torch.load(path, weights_only=True)
-    except pickle.UnpicklingError:
-        # a pickled container object (the reference's format): loading it runs the pickle, as torch_geometric's
-        # own users do for graph.pt -- only for files from a source the caller trusts
+    except pickle.UnpicklingError as e:
+        if not trusted:
+            raise ValueError(
+                f"{path} is not in the portable format and can only be read by executing its pickle; "
+                "pass trusted=True if the file comes from a source you trust") from e
         return torch.load(path, weights_only=False)
     return from_portable(content)

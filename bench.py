@@ -2,6 +2,7 @@
 """Benchmark of the graph-construction hot path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...                         (starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" builds the whole graph of the workload from node coordinates that are already
@@ -21,18 +22,18 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from anemoi_graphs_amd import distributed, grids, profiling, settings  # noqa: E402
-from anemoi_graphs_amd.distributed import BandGraphBuilder, ShardedGraphBuilder, band_bounds  # noqa: E402
+# numpy, torch and the package are imported by run(): a process that only starts the ranks of a multi-GPU run
+# (launch_ranks) loads nothing that could touch a GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 WORKLOADS = {
@@ -48,7 +49,6 @@ WORKLOADS = {
 }
 STRETCHED_DEFAULT_NODES = {"stretched_1km": 5.0e8, "stretched_small": 3.0e6}
 STRETCHED_SPACING_KM = {"stretched_1km": (9.0, 1.0), "stretched_small": (90.0, 10.0)}
-BINNINGS_DATA, BINNINGS_HIDDEN = 2.0, 2.0  # binning calls per build, by node set
 CUTOFF_FACTOR = 0.6
 KNN_K = 3
 X_HOPS = 1
@@ -59,23 +59,27 @@ def algorithmic_bytes(kernel: str, sizes: dict) -> float:
     set read once), edge ids are int32 pairs (8 B/edge), attributes are float32 length + float32
     direction pair (12 B/edge)."""
     nd, nh = sizes["n_data"], sizes["n_hidden"]
-    if kernel == "ag_knn_cell_kernel":  # decoder: hidden sources, data targets, k ids per target written
-        return 8.0 * nh + 8.0 * nd + 4.0 * KNN_K * nd
-    if kernel == "ag_knn_cell_kernel_self":  # reference distance: hidden -> hidden, one distance per node
-        return 8.0 * nh + 8.0 * nh + 8.0 * nh
-    if kernel in ("ag_radius_count_kernel", "ag_radius_fill_kernel"):
-        out = 8.0 * sizes["e_enc"] if "fill" in kernel else 8.0 * nh
-        return 8.0 * nd + 8.0 * nh + out
+    if kernel == "ag_knn_cell_kernel":  # decoder: hidden sources, data targets, both rows of the edge list written
+        return 8.0 * nh + 8.0 * nd + 8.0 * sizes["e_dec"]
+    if kernel in ("ag_radius_count_kernel", "ag_radius_tile_kernel"):
+        # the search of the cut-off query: both node sets read, a count per target written
+        return 8.0 * nd + 8.0 * nh + 8.0 * nh
+    if kernel == "ag_radius_copy_kernel":  # the rows the search kept, to their place in the edge list
+        return 4.0 * sizes["e_enc"] + 8.0 * sizes["e_enc"]
     if kernel == "ag_edge_attrs_kernel":
         # one fused launch per edge set (3 per build), averaged.  Per edge: 8 B of ids read, 2 x 8 B of
         # endpoint coordinates gathered, 4 B of length and 8 B of direction written = 36 B.
         return 36.0 * sizes["e_total"] / 3.0
     if kernel in ("ag_bin_count_kernel", "ag_bin_scatter_kernel"):
-        # binning calls of a build, averaged (the data nodes and the hidden nodes are binned twice each): count
-        # reads coordinates and writes a cell id per point; scatter reads both and writes coordinates + id in cell
-        # order
-        n = (BINNINGS_DATA * nd + BINNINGS_HIDDEN * nh) / (BINNINGS_DATA + BINNINGS_HIDDEN)
-        return (12.0 if kernel.endswith("count") else 24.0) * n
+        # binning calls of a build, averaged (the data nodes once -- the binning is kept and serves the encoder as
+        # sources and the decoder as targets -- and the hidden nodes once, as the decoder's sources): count reads
+        # coordinates and writes (cell, slot) per point; scatter reads all three and writes (unit vector, id) + id
+        n = (nd + nh) / 2.0
+        return (16.0 if kernel.endswith("count_kernel") else 36.0) * n
+    if kernel == "ag_normalise_apply_kernel":  # the lengths of an edge set, read and written once (3 launches per build)
+        return 8.0 * sizes["e_total"] / 3.0
+    if kernel == "ag_ms_place_kernel":
+        return 4.0 * nh + 8.0 * sizes["e_proc"]
     return 0.0
 
 
@@ -100,21 +104,33 @@ def unique_bytes(kernel: str, sizes: dict):
     return None
 
 
-def measured_traffic(kernel: str, workload: str):
-    """HBM bytes per launch of ``kernel`` from the newest committed rocprofv3 counter summary
-    (profiles/r*_hbm_traffic.json, written by tools/pmc_summary.py from separate FETCH_SIZE and
-    WRITE_SIZE passes over this same command); None when no pass covers the kernel."""
-    for path in sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"), reverse=True):
-        try:
-            entry = json.loads(path.read_text()).get(workload, {}).get("kernels", {}).get(kernel)
-        except (OSError, ValueError):
-            continue
-        if entry:
-            return float(entry["hbm_bytes_per_launch"]), path.name
-    return None, None
+def traffic_table(workload: str):
+    """{kernel: HBM bytes per launch} from the NEWEST committed rocprofv3 counter summary
+    (profiles/rNN_hbm_traffic.json, written by tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE
+    passes over this same command) and the name of that file.  The passes are labelled with the workload,
+    optionally followed by how the build was run (``o1280_r7_one_stream``).  An older round's file is never
+    consulted: when the newest summary does not cover the workload there is no measured traffic to quote."""
+    def round_of(path: Path) -> int:
+        m = re.match(r"r(\d+)_", path.name)
+        return int(m.group(1)) if m else -1
+
+    files = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"), key=round_of)
+    if not files:
+        return {}, None
+    newest = files[-1]
+    try:
+        doc = json.loads(newest.read_text())
+    except (OSError, ValueError):
+        return {}, None
+    labels = [k for k in doc if k == workload or k.startswith(workload + "_")]
+    if not labels:
+        return {}, None
+    label = workload if workload in labels else sorted(labels)[0]
+    table = {k: float(v["hbm_bytes_per_launch"]) for k, v in doc[label].get("kernels", {}).items()}
+    return table, f"{newest.name}:{label}"
 
 
-def cpu_baseline(data: np.ndarray, hidden: np.ndarray) -> dict:
+def cpu_baseline(data, hidden) -> dict:
     """The reference's CPU path (scikit-learn / numpy / scipy, called as the reference calls them) on a bounded
     sample of the same workload, timed on this machine's host cores: the two searches and the two edge
     attributes of the sampled edges.  The mesh (TriNodes, MultiScaleEdges) is not in it: the reference builds it
@@ -158,23 +174,35 @@ def cpu_baseline(data: np.ndarray, hidden: np.ndarray) -> dict:
     }
 
 
-def host_tensor_step_ms(data_np: np.ndarray, resolution: int, steps: int = 2) -> float:
+def host_tensor_step(data_np, resolution: int, steps: int = 3):
     """One build in the package's DEFAULT mode, as the reference hands graphs around: node coordinates come as host
-    tensors, every edge list and attribute goes back to host memory (PCIe both ways inside the step)."""
+    tensors, every edge list and attribute goes back to host memory (PCIe both ways inside the step).  Returns
+    (milliseconds per build, bytes that crossed the link per build)."""
+    import torch
+
+    from anemoi_graphs_amd import settings
+    from anemoi_graphs_amd.distributed import ShardedGraphBuilder
+
     data_host = torch.from_numpy(data_np)
     builder = ShardedGraphBuilder(data_host, resolution, cutoff_factor=CUTOFF_FACTOR, num_nearest_neighbours=KNN_K,
                                   x_hops=X_HOPS)
     with settings.resident(False):
-        builder.build()
+        graph = builder.build()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            builder.build()
+            graph = builder.build()
         torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+        elapsed = time.perf_counter() - t0
+    moved = data_host.numel() * data_host.element_size()
+    for name in [*graph.node_types, *graph.edge_types]:
+        for key, value in graph[name].items():
+            if isinstance(value, torch.Tensor) and not (key == "x" and value is data_host):
+                moved += value.numel() * value.element_size()
+    return elapsed / steps * 1e3, moved
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -189,7 +217,70 @@ def main() -> None:
                     help="o1280-style workloads on N > 1 ranks: treat the coordinates as sharded (halo rows travel)")
     ap.add_argument("--profile", default="dominant", choices=["dominant", "all", "off"],
                     help="which kernel launches carry HIP events inside the timed region")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv) -> int:
+    """``--gpus N`` without a launcher: start N fresh processes -- ``python -m torch.distributed.run``, one rank
+    per GPU -- and hand on rank 0's JSON line.  This process has not touched a GPU (it has not even imported torch)
+    and never will: it only waits for the children and returns their exit code, or 1 when the line is missing or
+    does not report N ranks."""
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)  # (stderr passes through)
+    line = None
+    for raw in proc.stdout.splitlines():
+        raw = raw.strip()
+        if raw.startswith("{") and '"metric"' in raw:
+            line = raw
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: the launcher of the {args.gpus} ranks ended with code {proc.returncode}\n")
+        return proc.returncode
+    if line is None:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        return 1
+    try:
+        ranks = int(json.loads(line).get("n_gpus", -1))
+    except ValueError:
+        ranks = -1
+    if ranks != args.gpus:
+        sys.stderr.write(f"bench.py: the result line reports {ranks} ranks, --gpus asked for {args.gpus}\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def kernel_table(warm_ms: dict, sizes: dict, traffic: dict, top: int = 5) -> dict:
+    """The longest kernels of one fully event-timed build: average launch duration, compulsory bytes, the fraction
+    of the HBM peak those bytes make, and (where the committed counter summary covers the kernel) measured traffic
+    per launch and its ratio to the compulsory bytes."""
+    rows = {}
+    ranked = sorted(((k, v) for k, v in warm_ms.items() if k.startswith("ag_") and v[0] > 0),
+                    key=lambda kv: kv[1][1], reverse=True)
+    for name, (launches, total_ms) in ranked[:top]:
+        avg_ms = total_ms / launches
+        nbytes = algorithmic_bytes(name, sizes)
+        row = {"launches": launches, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": nbytes or None}
+        if nbytes and avg_ms > 0:
+            row["frac"] = round(nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if name in traffic:
+            row["traffic"] = traffic[name]
+            if nbytes:
+                row["traffic_ratio"] = round(traffic[name] / nbytes, 2)
+        rows[name] = row
+    return rows
+
+
+def run(args) -> int:
+    import torch
+
+    from anemoi_graphs_amd import distributed, grids, profiling, settings
+    from anemoi_graphs_amd.distributed import BandGraphBuilder, ShardedGraphBuilder, band_bounds
 
     # stdout carries the one JSON line and nothing else: whatever libraries write to file descriptor 1
     # (RCCL prints a version banner there when the first communicator is created) goes to stderr
@@ -200,12 +291,14 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     # rehearsal knobs for a one-GPU machine: AG_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and
     # AG_BENCH_BACKEND=gloo exchanges through host memory (RCCL refuses two ranks on one GPU)
     if os.environ.get("AG_BENCH_ONE_DEVICE"):
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible); "
+                         "one rank per GPU is the rule (AG_BENCH_ONE_DEVICE=1 AG_BENCH_BACKEND=gloo rehearses on one)")
     backend = os.environ.get("AG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -223,8 +316,12 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        group_ranks = dist.get_world_size()
+        if group_ranks != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {group_ranks} ranks, --gpus asked for {args.gpus}")
     else:
         dist = None
+        group_ranks = 1
 
     grid_name, resolution = WORKLOADS[args.workload]
     stretched = grid_name == "stretched"
@@ -258,7 +355,7 @@ def main() -> None:
 
     with settings.resident(True):
         graph = None
-        # every kernel is event-timed during the warm-up (per-kernel table, choice of the dominant
+        # every kernel is event-timed during one untimed build (per-kernel table, choice of the dominant
         # kernel); in the timed region only the dominant kernel's launches carry events
         for _ in range(args.warmup):
             graph = builder.build()
@@ -272,7 +369,7 @@ def main() -> None:
         builder.timer.enabled = False
         warm_ms = profiling.collect()
         # the dominant hand-written kernel among those with a stated algorithmic byte count
-        probe = {"n_data": 1, "n_hidden": 1, "e_enc": 1, "e_total": 1}
+        probe = {"n_data": 1, "n_hidden": 1, "e_enc": 1, "e_dec": 1, "e_proc": 1, "e_total": 1}
         own = {k: v for k, v in warm_ms.items() if k.startswith("ag_") and algorithmic_bytes(k, probe) > 0.0}
         dominant = max(own.items(), key=lambda kv: kv[1][1])[0] if own else None
         profiling.enable(args.profile != "off", only=None if args.profile == "all" else dominant)
@@ -286,7 +383,7 @@ def main() -> None:
         profiling.enable(False)
         # A single-GPU build runs its edge sets on two streams: in the timed region the dominant kernel shares the
         # GPU with the kernels of the other stream, and its launches take longer than they do alone.  Its duration
-        # alone -- what the kernel itself achieves -- is measured afterwards, over builds on one stream.
+        # alone is measured afterwards, over builds on one stream, and reported beside the timed-region figure.
         isolated_ms = None
         if world == 1 and not stretched and getattr(builder, "overlap_processor", False) and dominant and args.profile != "off":
             builder.overlap_processor = False
@@ -319,9 +416,15 @@ def main() -> None:
         if dist is not None:
             distributed.shutdown(dist)
             dist.destroy_process_group()
-        return
+        return 0
 
     ms_per_step = elapsed / args.steps * 1e3
+    per_rank = dict(sizes)
+    if stretched and world > 1:  # a launch of a band build works on one rank's band
+        for key in ("n_data", "e_enc", "e_dec"):
+            per_rank[key] = sizes[key] / world
+        per_rank["e_total"] = per_rank["e_enc"] + per_rank["e_dec"] + e_proc
+    traffic_by_kernel, traffic_src = traffic_table(args.workload) if world == 1 else ({}, None)
     # dominant kernel of the timed region, by total device time (HIP events on the launch stream)
     roofline = None
     if kernel_ms and dominant in kernel_ms:
@@ -330,24 +433,21 @@ def main() -> None:
         name = dominant
         launches, total_ms = kernel_ms[name]
         avg_ms = total_ms / max(launches, 1)
-        per_rank = dict(sizes)
-        if stretched and world > 1:  # a launch of a band build works on one rank's band
-            for key in ("n_data", "e_enc", "e_dec"):
-                per_rank[key] = sizes[key] / world
-            per_rank["e_total"] = per_rank["e_enc"] + per_rank["e_dec"] + e_proc
         nbytes = algorithmic_bytes(name, per_rank)
         achieved = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(name, args.workload) if world == 1 else (None, None)
         strict = unique_bytes(name, per_rank)
         total_bytes = build_bytes(sizes)
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_by_kernel.get(name),
+            "traffic_source": traffic_src if name in traffic_by_kernel else None,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": nbytes,
+            "measured": "HIP events on the launch stream around every launch of the kernel inside the timed region"
+                        + (" (two streams: the kernel shares the GPU with the kernels of the other stream)"
+                           if isolated_ms else ""),
             # the whole build against the same roofline: its compulsory bytes over the wall time of a step
             "build_bytes": total_bytes,
             "build_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 5),
-            "kernels_ms_untimed_profiled_step": {k: round(v[1], 4) for k, v in sorted(warm_ms.items())},
             "launches_per_build": int(sum(v[0] for v in warm_ms.values())),
         }
         if strict is not None and avg_ms > 0:
@@ -355,25 +455,20 @@ def main() -> None:
             roofline["unique_bytes_per_launch"] = strict
             roofline["frac_unique_bytes"] = round(strict / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if isolated_ms and name in isolated_ms and isolated_ms[name][1] > 0:
-            # Two streams: the roofline figures describe the kernel, so they are taken from its launches alone (the
-            # same builds on one stream, run after the timed region); what the same launches took in the timed
-            # region, beside the kernels of the other stream, is stated next to them.
             iso_launches, iso_total = isolated_ms[name]
             iso_avg = iso_total / max(iso_launches, 1)
-            roofline["timed_region"] = {
-                "concurrent_streams": 2, "avg_launch_ms": roofline["avg_launch_ms"], "launches": launches,
-                "achieved": roofline["achieved"], "frac": roofline["frac"],
-            }
-            roofline["measured"] = ("the kernel's launches alone: the same builds on one stream (--no-overlap), run after "
-                                    "the timed region; timed_region: the launches of the timed region, where the "
-                                    "kernel shares the GPU with the kernels of the second stream")
-            roofline.update({
+            roofline["isolated"] = {
+                "what": "the kernel's launches alone: the same builds on one stream (--no-overlap), run after the "
+                        "timed region",
                 "avg_launch_ms": round(iso_avg, 4), "launches": iso_launches,
                 "achieved": round(nbytes / (iso_avg * 1e-3) / 1e9, 2),
                 "frac": round(nbytes / (iso_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            })
-            if strict is not None:
-                roofline["frac_unique_bytes"] = round(strict / (iso_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            }
+        # the longest kernels of one untimed build in which every launch carried events
+        roofline["kernels"] = kernel_table(warm_ms, per_rank, traffic_by_kernel)
+        roofline["kernels_source"] = ("one untimed build with HIP events on every launch; traffic: "
+                                      + (traffic_src or "no committed counter summary covers this workload"))
+        roofline["kernels_ms_untimed_profiled_step"] = {k: round(v[1], 4) for k, v in sorted(warm_ms.items())}
 
     if stretched:
         parallelism = "single GPU" if world == 1 else f"latitude bands x{world}, band-local input and output, halo rows only"
@@ -387,6 +482,8 @@ def main() -> None:
         "value": round(e_total / (elapsed / args.steps) / 1e6, 3),
         "unit": "Medges/s",
         "n_gpus": world,
+        "rccl_ranks": group_ranks,
+        "backend": (backend if dist is not None else "none (one process)"),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
@@ -412,9 +509,12 @@ def main() -> None:
         out["phases_ms_rank0"] = {k: round(v, 4) for k, v in phase_ms.items()}
     if world == 1 and not stretched:
         if not args.no_host_tensors:
-            out["ms_per_step_host_tensors"] = round(host_tensor_step_ms(data_np, resolution), 3)
-            out["ms_per_step_host_tensors_note"] = ("the package's default mode, PCIe inside the step: coordinates from "
-                                                    "host tensors, edge lists and attributes back to host memory; never `value`")
+            host_ms, moved = host_tensor_step(data_np, resolution)
+            out["ms_per_step_host_tensors"] = round(host_ms, 3)
+            out["pcie_gb_s"] = round(moved / (host_ms * 1e-3) / 1e9, 2)
+            out["ms_per_step_host_tensors_note"] = (
+                "the package's default mode, PCIe inside the step: coordinates from host tensors, edge lists and "
+                f"attributes back to host memory ({moved / 1e6:.0f} MB over the link per build); never `value`")
         if not args.no_cpu_baseline:
             hidden_np = graph["hidden"].x.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(data_np, hidden_np)
@@ -423,7 +523,18 @@ def main() -> None:
     if dist is not None:
         distributed.shutdown(dist)
         dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

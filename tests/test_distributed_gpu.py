@@ -156,3 +156,31 @@ def test_band_build_of_a_stretched_grid_equals_single(device, tmp_path, resoluti
     for p in got:
         for suffix in ("", "_len", "_dir"):
             assert np.array_equal(p["hidden_to_hidden" + suffix], want["hidden_to_hidden" + suffix])
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N starts its own ranks
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("workload,extra", [("stretched_small", []), ("o96_r4", []), ("o96_r4", ["--exchange-halo"])])
+def test_bench_starts_its_own_ranks(device, workload, extra):
+    """The command shape the multi-GPU measurement uses, ``python bench.py --gpus 2 ...`` with no launcher around
+    it: the parent starts two fresh rank processes (before it has touched a GPU) and hands on rank 0's line.  On
+    this one-GPU machine both ranks share GPU 0 and exchange through host memory (gloo)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, AG_BENCH_ONE_DEVICE="1", AG_BENCH_BACKEND="gloo")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    proc = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "1",
+                           "--warmup", "1", *extra], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
+    assert line["value"] > 0 and line["steps"] == 1
+    assert "phases_ms_rank0" in line
