@@ -68,7 +68,7 @@ def test_traffic_table_takes_the_newest_round_only(tmp_path, monkeypatch):
 def test_algorithmic_bytes_follow_the_stated_units():
     sizes = {"n_data": 1000, "n_hidden": 100, "e_enc": 5000, "e_dec": 3000, "e_proc": 600, "e_total": 8600}
     assert bench.algorithmic_bytes("ag_knn_cell_kernel", sizes) == 8 * 100 + 8 * 1000 + 8 * 3000
-    assert bench.algorithmic_bytes("ag_radius_tile_kernel", sizes) == 8 * 1000 + 8 * 100 + 8 * 100
+    assert bench.algorithmic_bytes("ag_radius_grouped_kernel", sizes) == 8 * 1000 + 8 * 100 + 8 * 100
     assert bench.algorithmic_bytes("ag_edge_attrs_kernel", sizes) == 36 * 8600 / 3
     rows = bench.kernel_table({"ag_edge_attrs_kernel": (3, 0.3), "ag_x": (1, 0.5), "rocprim": (1, 9.0)}, sizes,
                               {"ag_edge_attrs_kernel": 2.0 * 36 * 8600 / 3})

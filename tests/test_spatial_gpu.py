@@ -100,6 +100,15 @@ def test_reference_distance_golden(device, golden):
     assert float(ops.nn_maxdist(torch.from_numpy(g["data"]).to(device)).item()) == pytest.approx(float(g["refdist_data"]), rel=1e-13)
 
 
+@pytest.fixture(params=["callers_order", "group_order"])
+def radius_path(request, monkeypatch):
+    """The two orders in which the count pass of the cut-off query takes its targets: the caller's, and sorted into
+    groups of neighbours (forced here whatever the sizes; the library reads the variable at every call).  Both must
+    give the same edge list."""
+    monkeypatch.setenv("AG_RADIUS_GROUPED", "0" if request.param == "callers_order" else "1")
+    return request.param
+
+
 def _radius_case(src, tgt, radius, device):
     e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius).cpu().numpy()
     assert np.array_equal(e, h.canonical(e)), "rows must be target-major with ascending source ids"
@@ -110,7 +119,7 @@ def _radius_case(src, tgt, radius, device):
 
 
 @pytest.mark.parametrize("radius", [0.0, 0.01, 0.05, 0.4, 2.0, 3.1])
-def test_radius_random(device, radius):
+def test_radius_random(device, radius, radius_path):
     src, tgt = grids.random_sphere(20000, seed=21), grids.random_sphere(1500, seed=22)
     if radius > 1.0:
         src, tgt = src[:2000], tgt[:300]
@@ -119,7 +128,7 @@ def test_radius_random(device, radius):
     print("radius", radius, res)
 
 
-def test_radius_whole_sphere(device):
+def test_radius_whole_sphere(device, radius_path):
     # radius >= pi: every pair.  (scikit-learn's threshold sin^2(r/2) is not monotonic beyond pi and
     # drops near-antipodal pairs there; a cut-off radius beyond pi is meaningless, so the library
     # saturates instead.)
@@ -128,7 +137,7 @@ def test_radius_whole_sphere(device):
     assert e.shape[1] == 300 * 200
 
 
-def test_radius_regular(device):
+def test_radius_regular(device, radius_path):
     data, hidden = grids.regular(2.0), grids.fibonacci_sphere(642)
     radius = rp.cutoff_radius(hidden, 0.6)
     print(_radius_case(data, hidden, radius, device))
@@ -136,7 +145,7 @@ def test_radius_regular(device):
     print(_radius_case(hidden, hidden, rp.cutoff_radius(hidden, 1.0), device))
 
 
-def test_radius_golden(device, golden):
+def test_radius_golden(device, golden, radius_path):
     g = golden("regular_2deg")
     src, tgt, radius = g["data"], g["hidden"], float(g["enc_cutoff06_radius"])
     e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), radius).cpu().numpy()
@@ -149,7 +158,7 @@ def test_radius_golden(device, golden):
 
 
 @pytest.mark.parametrize("ns,nt,radius", [(200000, 400, 0.08), (200000, 300, 0.5), (60000, 50, 2.5)])
-def test_radius_long_rows(device, ns, nt, radius):
+def test_radius_long_rows(device, ns, nt, radius, radius_path):
     """Rows of hundreds to tens of thousands of sources: beyond what the count pass keeps, ordered by
     the segmented sort (mixed with short and empty rows: half the targets sit in a source-free cap)."""
     src = grids.random_sphere(ns, seed=31)
@@ -163,7 +172,7 @@ def test_radius_long_rows(device, ns, nt, radius):
     print("long rows", radius, res, "max row", rows.max(), "empty rows", int((rows == 0).sum()))
 
 
-def test_radius_rows_of_every_length_in_one_query(device):
+def test_radius_rows_of_every_length_in_one_query(device, radius_path):
     """Sources clustered around a point: the rows of one query run from empty through a few hundred entries (kept by
     the count pass), a thousand (sorted in LDS by the fill pass) to tens of thousands (the segmented sort)."""
     src, tgt = _clustered(300_000, 61), _clustered(2_500, 62)
@@ -181,7 +190,7 @@ def test_radius_rows_of_every_length_in_one_query(device):
     print("mixed rows", res, "max row", rows.max(), "rows in LDS", int(((rows > 256) & (rows <= 1024)).sum()))
 
 
-def test_radius_o1280_to_r4(device):
+def test_radius_o1280_to_r4(device, radius_path):
     """A coarse hidden mesh under a dense data grid: every row has thousands of entries."""
     data = grids.octahedral(320)
     hidden, _ = rp.tri_nodes(3)
@@ -200,7 +209,7 @@ def _clustered(n, seed):
 
 @pytest.mark.parametrize("n_src,n_tgt,seed", [(200_000, 3_000, 0), (5_000, 5_000, 1), (300, 40, 2), (50_000, 1, 3)])
 @pytest.mark.parametrize("scale", [1.0, 0.3, 4.0, 1e-6, 1e6])
-def test_radius_query_on_a_kept_binning(device, n_src, n_tgt, seed, scale):
+def test_radius_query_on_a_kept_binning(device, n_src, n_tgt, seed, scale, radius_path):
     """The cut-off query gives the same edge list whether it bins its sources itself or is handed a binning the
     caller keeps, whatever the cell size of that binning (ag_radius_count_binned / ag_radius_fill_binned)."""
     src, tgt = _clustered(n_src, seed), grids.random_sphere(n_tgt, seed=100 + seed)
@@ -423,3 +432,69 @@ def test_knn_over_regions_of_any_size(device, seed):
     np.testing.assert_allclose(got_d[keep], want_d[keep], rtol=1e-12, atol=1e-15)
     assert np.all(np.isinf(got_d[~inside & ~edge])) and np.all(ids_b.cpu().numpy()[~inside & ~edge] == -1)
     print("regions", seed, ns, nt, k, half, int(where), ops.point_density(s), int(inside.sum()))
+
+
+@pytest.mark.parametrize("case", ["o320_r5", "era5like_r4", "clustered", "kept_fine", "kept_coarse", "polar_targets"])
+def test_radius_encoder_shaped_queries(device, case, radius_path):
+    """The cut-off query on configurations shaped like encoders, rows of 40 to 200 entries (the row sort's network
+    for the first 64 entries, the placement of the entries beyond, the ranking of long rows): a reduced Gaussian grid
+    under an icosphere, a regular grid with crowded polar cells, clustered node sets, kept binnings with cells finer
+    and coarser than the radius asks for (windows of four bands), targets on and around the poles.  Canonical order,
+    and equal to scikit-learn's rows on a sample of the targets."""
+    if case == "o320_r5":
+        src, tgt = grids.octahedral(320), rp.tri_nodes(5)[0]
+        radius, scale = rp.cutoff_radius(tgt, 0.6), None
+    elif case == "era5like_r4":
+        src, tgt = grids.regular(0.5), rp.tri_nodes(4)[0]
+        radius, scale = rp.cutoff_radius(tgt, 0.6), None
+    elif case == "clustered":
+        src, tgt = _clustered(400_000, 71), _clustered(30_000, 72)
+        radius, scale = 0.012, None
+    elif case in ("kept_fine", "kept_coarse"):
+        src, tgt = grids.random_sphere(300_000, seed=73), grids.random_sphere(20_000, seed=74)
+        radius, scale = 0.02, (0.55 if case == "kept_fine" else 2.5)
+    else:
+        src = grids.random_sphere(200_000, seed=75)
+        rng = np.random.default_rng(76)
+        lat = np.concatenate([np.full(50, np.pi / 2), np.full(50, -np.pi / 2), np.pi / 2 - rng.uniform(0, 0.05, 6000),
+                              -np.pi / 2 + rng.uniform(0, 0.05, 6000)])
+        tgt = np.stack([lat, rng.uniform(0, 2 * np.pi, lat.size)], axis=1).astype(np.float32)
+        radius, scale = 0.03, None
+    s, t = torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device)
+    kept = None if scale is None else ops.bin_points(s, scale * ops.radius_cell(len(src), radius))
+    e = ops.radius_edges(s if kept is None else None, t, radius, src_binning=kept).cpu().numpy()
+    assert np.array_equal(e, h.canonical(e))
+    rows = np.bincount(e[1], minlength=len(tgt))
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(len(tgt), size=min(len(tgt), 400), replace=False))
+    ref = rp.radius_edges(src, tgt[pick], radius)
+    keep = np.isin(e[1], pick)
+    got = np.stack([e[0][keep], np.searchsorted(pick, e[1][keep])]).astype(e.dtype)
+    res = h.compare_edge_sets(src, tgt[pick], got, ref, radius)
+    assert res["bad"] == 0, res
+    print(case, "edges", e.shape[1], "rows: mean", rows.mean(), "over 64:", int((rows > 64).sum()), "over 128:",
+          int((rows > 128).sum()), res)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 63, 64, 65, 66, 90, 127, 128, 129, 200, 256])
+def test_radius_rows_of_exact_lengths_are_sorted(device, n, radius_path):
+    """Rows of exactly n entries, for the lengths around which the row sort changes method (one key per lane: 64;
+    placement of the entries beyond: 65 ... 128; ranking: 129 ...), with source ids in descending, ascending and
+    shuffled order of their position: every target sees the same n sources."""
+    rng = np.random.default_rng(n)
+    centre = np.array([0.4, 1.3])
+    near = centre + 1.0e-3 * rng.uniform(-1, 1, (n, 2))
+    far = grids.random_sphere(5000, seed=n)
+    far = far[np.abs(far[:, 0] - 0.4) > 0.2]
+    for order in ("shuffled", "ascending", "descending"):
+        src = np.concatenate([far, near]).astype(np.float32)
+        perm = rng.permutation(len(src)) if order == "shuffled" else np.arange(len(src))
+        if order == "descending":
+            perm = perm[::-1]
+        src = np.ascontiguousarray(src[perm])
+        tgt = (centre + 1.0e-3 * rng.uniform(-1, 1, (40, 2))).astype(np.float32)
+        e = ops.radius_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), 0.01).cpu().numpy()
+        assert e.shape[1] == 40 * n
+        assert np.array_equal(e, h.canonical(e)), (n, order)
+        want = np.sort(np.flatnonzero(np.isin(perm, np.arange(len(far), len(far) + n))))
+        assert np.array_equal(e[0].reshape(40, n), np.broadcast_to(want, (40, n)))
