@@ -289,6 +289,44 @@ def multiscale_edges_one_hop(resolutions: list[int], node_ordering: np.ndarray) 
     return canonical_sort(pairs.T.astype(np.int32))
 
 
+def multiscale_edges_hops(resolutions: list[int], x_hops: int, node_ordering: np.ndarray) -> np.ndarray:
+    """``multiscale_edges`` on the complete icosphere (TriNodes) for any ``x_hops``, without the per-vertex
+    networkx loop, for meshes too large for it (r6, r7).
+
+    ``nx.ego_graph(mesh, i, radius=x_hops, center=False)`` (generate/tri_icosahedron.py:218-222) is the set of
+    vertices at most ``x_hops`` mesh edges from i, without i: with A the boolean adjacency matrix of the level's
+    unique edges, the non-zero pattern of (A + I)^x_hops with the diagonal removed.  The matrix power is taken
+    by repeated sparse products (frontier expansion); a level's vertices map to the final mesh's nodes with the
+    same vertex id (:185) and node ids are positions in ``node_ordering`` (edges/builder.py:453); the DiGraph
+    merges the levels (:187).  ``tests/test_oracle_golden.py`` proves this function equal to the networkx
+    restatement on the meshes that one handles.  Returns int32 [2,E] sorted by (target, source)."""
+    import scipy.sparse as sp
+
+    from . import icosphere as ico
+
+    node_ordering = np.asarray(node_ordering)
+    rank = np.empty(len(node_ordering), dtype=np.int64)
+    rank[node_ordering] = np.arange(len(node_ordering))
+    pairs = []
+    for resolution in sorted(set(int(r) for r in resolutions)):
+        v, f = ico.icosphere(resolution)
+        e = np.unique(ico.face_edges(f), axis=0)
+        n = len(v)
+        ones = np.ones(len(e), dtype=np.int8)
+        step = (sp.coo_matrix((ones, (e[:, 0], e[:, 1])), shape=(n, n))
+                + sp.coo_matrix((ones, (e[:, 1], e[:, 0])), shape=(n, n)) + sp.identity(n, dtype=np.int8)).tocsr()
+        reach = step.copy()
+        for _ in range(x_hops - 1):
+            reach = reach @ step
+            reach.data[:] = 1  # (boolean: the counts of walks are of no interest and would overflow)
+        reach = reach.tocoo()
+        keep = reach.row != reach.col
+        # (neighbour -> node), as create_node_neighbours_list lists them (:298-310); the relation is symmetric
+        pairs.append(np.stack([rank[reach.col[keep]], rank[reach.row[keep]]], axis=1))
+    pairs = np.unique(np.concatenate(pairs, axis=0), axis=0)  # columns (source, target)
+    return canonical_sort(pairs.T.astype(np.int32))
+
+
 def multiscale_edges(resolutions: list[int], x_hops: int, node_ordering: np.ndarray, node_coords: np.ndarray | None = None,
                      mask_reference: np.ndarray | None = None, margin_radius_km: float = 100.0) -> np.ndarray:
     """add_edges_to_nx_graph (generate/tri_icosahedron.py:165-188), get_neighbours_within_hops

@@ -21,7 +21,7 @@ DOC_FACES = {0: 20, 1: 80, 2: 320, 3: 1280, 4: 5120, 5: 20480, 6: 81920}
 DOC_MULTILEVEL_EDGES = {0: 60, 1: 300, 2: 1260, 3: 5100, 4: 20460, 5: 81900, 6: 327660}
 
 
-@pytest.mark.parametrize("r", [0, 1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("r", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_icosphere_matches_restatement(device, r):
     """Vertices, faces and per-level edges bit-equal to the numpy restatement of trimesh, up to the headline
     mesh (r7); lat/lon within one float32 ulp (device asin / atan2 against the host libm's), with the number of
@@ -144,6 +144,20 @@ def test_multiscale_one_hop_oracle_full_size(device, r, levels):
     ops._lib.check(lib.ag_multiscale_fill(r, lv, len(levels), 1, n, ops._ptr(e2[0]), ops._ptr(e2[1]), ops._ptr(ws),
                                           ws.numel(), ops._stream(device)), "fill")
     assert np.array_equal(e2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("r,hops,levels", [(6, 2, None), (7, 2, None), (6, 3, None), (7, 2, [0, 4, 7]), (5, 4, None)])
+def test_multiscale_more_hops_on_the_benchmark_meshes(device, r, hops, levels):
+    """x_hops >= 2 on the meshes of the benchmark configurations (generate/tri_icosahedron.py:191-224: the
+    neighbours within x_hops mesh edges on every level), every edge against the sparse-matrix oracle (proved equal
+    to the networkx restatement on small meshes by tests/test_oracle_golden.py)."""
+    levels = list(range(r + 1)) if levels is None else levels
+    xyz, faces, latlon, order, rank, level_edges = ops.icosphere(r, device)
+    e = ops.multiscale_edges(r, levels, hops, rank, level_edges).cpu().numpy()
+    want = rp.multiscale_edges_hops(levels, hops, order.cpu().numpy())
+    assert e.shape == want.shape, (e.shape, want.shape)
+    assert np.array_equal(e, want)
+    print(f"r{r} x_hops={hops} levels={levels}: {e.shape[1]} edges")
 
 
 @pytest.mark.parametrize("r", [1, 3, 6, 7])

@@ -182,3 +182,18 @@ def test_uniform_weights_oracle_matches_reference(golden):
     n = gold["o32_x"].shape[0]
     np.testing.assert_array_equal(rp.uniform_weights(n, "l1"), gold["o32_uniform_l1"])
     np.testing.assert_array_equal(rp.uniform_weights(n), gold["o32_uniform_none"])
+
+
+@pytest.mark.parametrize("r,hops,levels", [(2, 1, None), (3, 2, None), (4, 2, None), (3, 3, None), (4, 3, [1, 3, 4]),
+                                           (2, 4, None)])
+def test_frontier_expansion_oracle_equals_networkx_restatement(r, hops, levels):
+    """The sparse-matrix oracle for x_hops >= 2 (used on r6 / r7, where the per-vertex networkx loop of the
+    restatement takes hours) against that restatement on the meshes it handles; x_hops = 1 also against the
+    one-hop oracle."""
+    levels = list(range(r + 1)) if levels is None else levels
+    order = rp.tri_nodes(r)[1]
+    got = rp.multiscale_edges_hops(levels, hops, order)
+    want = rp.multiscale_edges(levels, hops, order)
+    assert np.array_equal(got, h.canonical(want))
+    if hops == 1:
+        assert np.array_equal(got, rp.multiscale_edges_one_hop(levels, order))
