@@ -19,6 +19,8 @@ _P = c_void_p  # every device pointer and the stream travel as void*
 SIGNATURES = {
     "ag_last_error": (c_char_p, []),
     "ag_version": (c_int, []),
+    "ag_status_take": (c_int, [ctypes.POINTER(c_int)]),
+    "ag_debug_poison_scans": (c_int, [c_int]),
     "ag_profile_enable": (c_int, [c_int]),
     "ag_profile_filter": (c_int, [ctypes.c_char_p]),
     "ag_profile_collect": (c_int, [ctypes.c_char_p, c_size_t]),

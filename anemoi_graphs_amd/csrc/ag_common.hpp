@@ -366,6 +366,12 @@ int ag_grid_bands(double delta);
 int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_reserve, int mult, bool want_pts,
                   hipStream_t stream, AgBinned* out);
 
+// The status word of the current device (device address; nullptr if it cannot be had) and the values it takes.
+int* ag_status_word();
+#define AG_STATUS_SCAN_GAVE_UP 1  // a single-launch scan met state words that were not clear, or waited in vain
+// Test hook (ag_debug_poison_scans): the kernels that clear the state words of a scan fill them with ones instead.
+bool ag_debug_scans_poisoned();
+
 // device-wide primitives (rocPRIM behind a plain interface)
 size_t ag_sort_u64_temp_bytes(int64_t n);
 int ag_sort_u64(void* d_temp, size_t temp_bytes, const uint64_t* d_in, uint64_t* d_out, int64_t n, int begin_bit,

@@ -213,6 +213,49 @@ int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The library's status word: one per device, set by a kernel that had to give up (a scan whose state words were
+// not clear) and by the kernels that found such a result and left safe, empty output in its place.  The host
+// reads and clears it where it synchronises anyway (ag_status_take).
+// ---------------------------------------------------------------------------------------------
+static __device__ int ag_status_word_storage[64];  // (a cache line of its own)
+#define AG_STATUS_MAX_DEVICES 64
+
+int* ag_status_word() {
+  static std::mutex mutex;
+  static int* address[AG_STATUS_MAX_DEVICES] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= AG_STATUS_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(mutex);
+  if (address[device] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ag_status_word_storage)) != hipSuccess) return nullptr;
+    address[device] = static_cast<int*>(p);  // (device memory of a code object starts out zeroed)
+  }
+  return address[device];
+}
+
+static bool ag_scans_poisoned = false;
+bool ag_debug_scans_poisoned() { return ag_scans_poisoned; }
+extern "C" int ag_debug_poison_scans(int on) {
+  ag_scans_poisoned = on != 0;
+  return AG_OK;
+}
+
+extern "C" int ag_status_take(int* status) {
+  AG_REQUIRE(status != nullptr, "ag_status_take: null pointer");
+  int* word = ag_status_word();
+  if (word == nullptr) return ag_fail(AG_ERR_HIP, "ag_status_take: the status word of the current device is not available");
+  int value = 0;
+  AG_HIP(hipMemcpy(&value, word, sizeof(int), hipMemcpyDeviceToHost));  // (waits for the work queued before it)
+  if (value != 0) {
+    const int zero = 0;
+    AG_HIP(hipMemcpy(word, &zero, sizeof(int), hipMemcpyHostToDevice));
+  }
+  *status = value;
+  return AG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Single-launch exclusive scan (chained tiles with decoupled look-back).
 //
 // Tiles take a ticket when they start, so a tile only ever waits for tiles that are already
@@ -233,7 +276,8 @@ int ag_zero_i32(int* d_ptr, int64_t n, hipStream_t stream) {
 // counts the missing predecessors as zero and goes on, so that every block of the launch ends whatever the state
 // words held (stale words of a workspace nobody cleared would otherwise be waited for for ever).  The tile that
 // writes the total writes -1 instead when the error word is set.  (A poll takes about 0.1 us: the limit is some
-// tenths of a second, far beyond any wait for a tile that is actually running.)
+// tenths of a second, far beyond any wait for a tile that is actually running.)  Whoever sets the error word also
+// sets the library's status word, which the host reports at its next synchronisation.
 #define AG_SCAN_SPIN_LIMIT (1 << 22)
 
 template <class T>
@@ -270,7 +314,8 @@ __device__ __forceinline__ void ag_scan_state_store(unsigned long long* p, unsig
 template <class T>
 __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* out, int64_t n,
                                                               unsigned long long* __restrict__ state, int want_max,
-                                                              long long* __restrict__ total_out, int spin_limit) {
+                                                              long long* __restrict__ total_out, int spin_limit,
+                                                              int* __restrict__ status) {
   constexpr int ITEMS = AgScanTile<T>::ITEMS;
   constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_PREFIX = 2ull << 62, VALUE = (1ull << 62) - 1ull;
   __shared__ unsigned s_tile;
@@ -283,7 +328,10 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
   const int64_t tile = s_tile;
   const int64_t ntiles = (n + 256 * ITEMS - 1) / (256 * ITEMS);
   if (tile >= ntiles) {  // a ticket beyond the tiles of this scan: the state words were not zero at launch
-    if (tid == 0) ag_scan_state_store(state + 3, 1ull);
+    if (tid == 0) {
+      ag_scan_state_store(state + 3, 1ull);
+      if (status != nullptr) *status = AG_STATUS_SCAN_GAVE_UP;
+    }
     return;
   }
   const int64_t first = tile * (256 * ITEMS) + int64_t(tid) * ITEMS;
@@ -352,7 +400,10 @@ __global__ __launch_bounds__(256) void ag_chained_scan_kernel(const T* in, T* ou
           if (idx >= 0 && (st >> 62) == 0ull) st = ag_scan_state_load(state + AG_SCAN_HEADER + idx, polls);
           if (polls >= spin_limit) {  // (wave-uniform) give up: see AG_SCAN_SPIN_LIMIT
             if ((st >> 62) == 0ull) st = FLAG_PREFIX;  // the missing predecessors count as zero; the look-back ends here
-            if (lane == 0) ag_scan_state_store(state + 3, 1ull);
+            if (lane == 0) {
+              ag_scan_state_store(state + 3, 1ull);
+              if (status != nullptr) *status = AG_STATUS_SCAN_GAVE_UP;
+            }
           }
         }
         const unsigned long long has_prefix = __ballot((st >> 62) == 2ull);
@@ -411,7 +462,7 @@ int ag_chained_scan_i32(const int* d_in, int* d_out, int64_t n, unsigned long lo
                         long long* d_total) {
   if (n <= 0) return AG_OK;
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int>, dim3(static_cast<unsigned>(ag_scan_tiles<int>(n))),
-            dim3(256), stream, d_in, d_out, n, d_state, 0, d_total, AG_SCAN_SPIN_LIMIT);
+            dim3(256), stream, d_in, d_out, n, d_state, 0, d_total, AG_SCAN_SPIN_LIMIT, ag_status_word());
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -421,7 +472,7 @@ int ag_chained_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n, unsigned
   if (n <= 0) return AG_OK;
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int64_t>,
             dim3(static_cast<unsigned>(ag_scan_tiles<int64_t>(n))), dim3(256), stream, d_in, d_out, n, d_state, want_max,
-            static_cast<long long*>(nullptr), AG_SCAN_SPIN_LIMIT);
+            static_cast<long long*>(nullptr), AG_SCAN_SPIN_LIMIT, ag_status_word());
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -437,7 +488,7 @@ extern "C" int ag_scan_i32(const int32_t* d_in, int32_t* d_out, int64_t n, unsig
   AG_REQUIRE(d_in && d_out && d_state, "ag_scan_i32: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AG_KERNEL("ag_chained_scan_kernel", ag_chained_scan_kernel<int>, dim3(static_cast<unsigned>(ag_scan_tiles<int>(n))),
-            dim3(256), s, d_in, d_out, n, d_state, 0, static_cast<long long*>(nullptr), spin_limit);
+            dim3(256), s, d_in, d_out, n, d_state, 0, static_cast<long long*>(nullptr), spin_limit, ag_status_word());
   AG_LAUNCH_CHECK();
   return AG_OK;
 }

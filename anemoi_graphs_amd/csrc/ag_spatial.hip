@@ -36,10 +36,11 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
                                                              int* __restrict__ off, double* __restrict__ win,
                                                              int* __restrict__ cell_count, int64_t ncount,
                                                              unsigned long long* __restrict__ scan_state,
-                                                             int64_t nstate) {
+                                                             int64_t nstate, unsigned long long state_fill) {
   const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
   for (int64_t i = gtid; i < ncount; i += gsize) cell_count[i] = 0;
-  for (int64_t i = gtid; i < nstate; i += gsize) scan_state[i] = 0ull;  // state of the scan of the counters
+  // state of the scan of the counters: zero (anything else only from the test hook ag_debug_poison_scans)
+  for (int64_t i = gtid; i < nstate; i += gsize) scan_state[i] = state_fill;
   if (blockIdx.x != 0) return;
   __shared__ int partial[1024];
   const int tid = threadIdx.x;
@@ -118,9 +119,29 @@ __global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, in
   }
 }
 
+// The scan of the cell counts leaves their total in cell_start[ncells]: every point was counted once, so it is n.
+// Anything else means the scan gave up (state words that were not clear) and the cell starts cannot be trusted --
+// some records would never be written, and the searches follow the ids they hold.  The binning is then left EMPTY
+// but sound: every cell without points, the records and ids in the points' own order (all initialised, all ids
+// valid), and the library's status word set, which the host turns into an error at its next synchronisation.
+#define AG_STATUS_BINNING_FAILED 2
 __global__ void ag_bin_scatter_kernel(const float2* __restrict__ pts, int64_t n, const int* __restrict__ cell_of,
-                                      const int* __restrict__ slot_of, const int* __restrict__ cell_start,
-                                      float4* __restrict__ out_pts, int* __restrict__ out_ids) {
+                                      const int* __restrict__ slot_of, int* __restrict__ cell_start, int64_t ncells,
+                                      float4* __restrict__ out_pts, int* __restrict__ out_ids, int* __restrict__ status) {
+  if (cell_start[ncells] != static_cast<int>(n)) {  // (the same for every thread of the launch: nobody writes that word)
+    const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t c = gtid; c < ncells; c += gsize) cell_start[c] = 0;
+    for (int64_t i = gtid; i < n; i += gsize) {
+      out_ids[i] = static_cast<int>(i);
+      if (out_pts != nullptr) {
+        const float2 p = pts[i];
+        const float3 u = ag_unit_vec(p.x, p.y);
+        out_pts[i] = make_float4(u.x, u.y, u.z, __int_as_float(static_cast<int>(i)));
+      }
+    }
+    if (gtid == 0 && status != nullptr) *status = AG_STATUS_BINNING_FAILED;
+    return;
+  }
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     const int pos = cell_start[cell_of[i]] + slot_of[i];
     out_ids[pos] = static_cast<int>(i);
@@ -208,7 +229,8 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   ag_bin_describe(c, n, nb, mult, out);
   const int64_t ncells_ub = out->ncells_ub;
   AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(ncells_ub + 1, 4096, 256)), dim3(1024), stream,
-            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1, c.scan_state, c.scan_words);
+            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1, c.scan_state, c.scan_words,
+            ag_debug_scans_poisoned() ? 0x40000000ull : 0ull);  // (poisoned: every tile draws a ticket beyond the last tile)
   AG_LAUNCH_CHECK();
   int rc = AG_OK;
   const int blocks = ag_blocks(n, 256, 16384);
@@ -218,7 +240,8 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   rc = ag_chained_scan_i32(c.cell_start, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> [ncells_ub]
   if (rc) return rc;
   AG_KERNEL("ag_bin_scatter_kernel", ag_bin_scatter_kernel, dim3(blocks), dim3(256), stream,
-            reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start, c.pts, c.ids);
+            reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start, ncells_ub, c.pts, c.ids,
+            ag_status_word());
   AG_LAUNCH_CHECK();
   return AG_OK;
 }
@@ -1689,7 +1712,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     const int64_t occ_cells = ag_grid_cells_ub(nb_occ);
     AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(occ_cells + 1, 4096, 256)), dim3(1024), stream,
               nb_occ, a.occ_grid.dlat, 1, w.occ_ncols, w.occ_off, w.occ_win, w.occ_count, occ_cells + 1,
-              static_cast<unsigned long long*>(nullptr), int64_t(0));
+              static_cast<unsigned long long*>(nullptr), int64_t(0), 0ull);
     AG_LAUNCH_CHECK();
     AG_KERNEL("ag_occupancy_count_kernel", ag_occupancy_count_kernel, dim3(ag_blocks(ns, 256, 16384)), dim3(256), stream,
               a.occ_grid, a.src, ns, w.occ_count);

@@ -58,8 +58,9 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (the handl
 
 
 def _stream(device: torch.device):
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    _USED_DEVICES.add(index)
     if _RAW_STREAM is not None:
-        index = device.index if device.index is not None else torch.cuda.current_device()
         return ctypes.c_void_p(_RAW_STREAM(index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -87,16 +88,52 @@ def _bad_word(device: torch.device) -> torch.Tensor:
     return word
 
 
+_USED_DEVICES: set[int] = set()  # devices a call of this module has launched work on
+
+
+def check_status(device: torch.device | None = None) -> None:
+    """Raise LibraryError if a kernel of the library had to give up since the last check (``ag_status_take``:
+    a prefix sum that met state words that were not clear, a binning that was left empty for that reason).
+    Synchronises with the device."""
+    lib = _lib.load()
+    indices = sorted(_USED_DEVICES) if device is None else [
+        device.index if device.index is not None else torch.cuda.current_device()]
+    failed = []
+    for index in indices:
+        with torch.cuda.device(index):
+            status = ctypes.c_int(0)
+            _lib.check(lib.ag_status_take(ctypes.byref(status)), "ag_status_take")
+        if status.value:
+            failed.append((index, status.value))
+    if failed:
+        what = {1: "a prefix sum gave up waiting for a tile (state words not cleared?)",
+                2: "a binning was left empty because the prefix sum of its cell counts did not add up"}
+        raise _lib.LibraryError("; ".join(f"cuda:{i}: {what.get(v, f'status {v}')}" for i, v in failed)
+                                + " -- the results of the calls since the last check are not valid")
+
+
 def check_ids(device: torch.device | None = None) -> None:
-    """Raise IndexError if a kernel met an id outside its table since the last check (synchronises)."""
+    """Raise IndexError if a kernel met an id outside its table since the last check, LibraryError if one had to
+    give up (``check_status``).  Synchronises."""
     words = list(_BAD_IDS.values()) if device is None else [_bad_word(device)]
     bad = False
     for word in words:
         if int(word.item()):
             word.zero_()
             bad = True
+    check_status(device)
     if bad:
         raise IndexError("index out of bounds: an edge_index or id array refers to a node that does not exist")
+
+
+def discard_checks() -> None:
+    """Read and drop whatever the error words hold (the caller is already reporting a failure of its own)."""
+    for word in _BAD_IDS.values():
+        word.zero_()
+    try:
+        check_status()
+    except _lib.LibraryError:
+        pass
 
 
 def _ids_checked(device: torch.device) -> None:
@@ -104,6 +141,15 @@ def _ids_checked(device: torch.device) -> None:
 
     if not settings.device_resident:
         check_ids(device)
+
+
+def _status_checked(device: torch.device) -> None:
+    """After a search or a binning: with graph tensors on the host the status is read at once (the results are
+    about to be copied anyway); resident builds read it when their context ends."""
+    from . import settings
+
+    if not settings.device_resident:
+        check_status(device)
 
 
 class Binning:
@@ -187,6 +233,7 @@ def bin_points(x: torch.Tensor, cell: float, device: torch.device | None = None)
     with _on(dev):
         buf = torch.empty(lib.ag_binning_bytes(n), dtype=torch.uint8, device=dev)
         _lib.check(lib.ag_binning_build(_ptr(xd), n, float(cell), _ptr(buf), buf.numel(), _stream(dev)), "ag_binning_build")
+    _status_checked(dev)
     return Binning(xd, buf, cell, tensor_key(src))
 
 
@@ -220,6 +267,7 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
                                   _ptr(out), _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_knn_binned",
             )
+            _status_checked(dev)
             res = (out,) + ((dist,) if return_dist else ()) + ((stats,) if return_stats else ())
             return res[0] if len(res) == 1 else res
         if tgt_density is None:  # (a bounded search with a binning of the targets: they are searched unbinned)
@@ -237,6 +285,7 @@ def knn(src: torch.Tensor, tgt: torch.Tensor, k: int, return_dist: bool = False,
                                   _ptr(dist), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev)),
                 "ag_knn_within",
             )
+    _status_checked(dev)
     res = (out,)
     if return_dist:
         res += (dist,)
@@ -273,6 +322,7 @@ def knn_edges(src: torch.Tensor, tgt: torch.Tensor, k: int, tgt_binning: Binning
                              _ptr(edge_index[1]), None, _ptr(ws), ws.numel(), _stream(dev)),
             "ag_knn_edges",
         )
+    _status_checked(dev)
     return edge_index
 
 
@@ -303,6 +353,7 @@ def nn_maxdist(x: torch.Tensor, density: float | None = None) -> torch.Tensor:
         out = torch.zeros((), dtype=torch.float64, device=dev)
         ws = _workspace(lib.ag_nn_maxdist_workspace_bytes(n, density), dev)
         _lib.check(lib.ag_nn_maxdist(_ptr(x), n, density, _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "ag_nn_maxdist")
+    _status_checked(dev)
     return out
 
 
@@ -333,8 +384,10 @@ def radius_edges(src: torch.Tensor, tgt: torch.Tensor, radius: float, src_binnin
             )
         num_edges, max_row = offsets[nt:].tolist()  # the one host synchronisation: output size, longest row
         if num_edges < 0:
+            discard_checks()
             raise _lib.LibraryError("ag_radius_count: the scan of the row lengths gave up waiting for a tile "
                                     "(workspace state not cleared?)")
+        _status_checked(dev)
         edge_index = torch.empty((2, num_edges), dtype=torch.int32, device=dev)
         if num_edges and src_binning is None:
             _lib.check(

@@ -21,8 +21,16 @@ def resident(flag: bool = True):
     device_resident = flag
     try:
         yield
-    finally:
+    except BaseException:
         device_resident = old
+        if flag and not old:
+            # the body failed for a reason of its own: what its kernels left in the error words belongs to this
+            # build and must not surface in a later, unrelated one -- read and dropped
+            from . import ops
+
+            ops.discard_checks()
+        raise
+    device_resident = old
     if flag and not old:
         from . import ops
 

@@ -45,6 +45,19 @@ int ag_profile_enable(int on);
 int ag_profile_filter(const char* kernel_name); /* NULL or "": every kernel; else only launches of that name */
 int ag_profile_collect(char* buf, size_t buf_bytes);
 
+/* Status of the current device (no counterpart in the reference).  The kernels never stop a launch half-way: one
+ * that cannot do its work -- a single-launch prefix sum that finds its state words not cleared or waits in vain
+ * for a tile (value 1), a binning whose cell starts did not add up to the number of points (value 2: the binning
+ * is then left EMPTY but sound, every record initialised, so that the searches that read it stay inside their
+ * arrays and find nothing) -- sets the status word of its device instead.  ag_status_take copies the word to
+ * *status and clears it; it waits for the device work queued before it.  The Python layer calls it wherever it
+ * synchronises for the caller and raises LibraryError on a non-zero value.
+ * ag_debug_poison_scans(1) is a test hook: until it is switched off, binning calls fill the state words of their
+ * prefix sum with ones instead of clearing them, so that the path above can be exercised with every kernel still
+ * ending normally. */
+int ag_status_take(int* status);
+int ag_debug_poison_scans(int on);
+
 /* ---------------------------------------------------------------------------------------
  * k nearest neighbours on the sphere.
  * Replaces NearestNeighbors(metric="haversine").fit(src).kneighbors_graph(tgt, k, "distance")
