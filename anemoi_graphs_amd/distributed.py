@@ -300,11 +300,21 @@ class ShardedGraphBuilder:
             if self.attributes:
                 b.register_attributes(graph, attrs)
 
+        def finished(graph):
+            # the working memory of the build -- the kept binning of the data nodes (190 MB for O1280), the cached
+            # reference distance and densities -- does not leave with the graph; what MultiScaleEdges and the tests
+            # of the node builders read (the mesh, the node order) stays, as after ``TriNodes.update_graph``
+            for name in graph.node_types:
+                for key in ("_binning", "_reference_distance", "_density"):
+                    if key in graph[name]:
+                        del graph[name][key]
+            return graph
+
         x = graph["hidden"].x
         if not (overlap and x.is_cuda):
             for b in builders:
                 run(b)
-            return graph
+            return finished(graph)
         # Two streams.  The processor edges need the hidden mesh and nothing else, and their kernels are many and
         # small (they wait for memory, not for compute units): they are queued on a second stream, behind the mesh,
         # and run beside the reference distance of the first.  The decoder search needs the binned data nodes -- which
@@ -323,7 +333,7 @@ class ShardedGraphBuilder:
             run(decoder)
         run(encoder)
         main.wait_stream(side)
-        return graph
+        return finished(graph)
 
     # ---------------------------------------------------------------------------------- sharded
     def _attrs(self, src_x, tgt_x, edge_index):

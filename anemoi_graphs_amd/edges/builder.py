@@ -28,7 +28,7 @@ def kept_binning(nodes: NodeStorage, cell: float | None, accept: tuple[float, fl
     None: whatever is kept, or None."""
     x = torch.as_tensor(nodes.x)
     kept = nodes["_binning"] if "_binning" in nodes else None
-    if isinstance(kept, ops.Binning) and kept.key == ops.tensor_key(x):
+    if isinstance(kept, ops.Binning) and kept.key.matches(x):
         if cell is None or accept[0] * cell <= kept.cell <= accept[1] * cell:
             return kept
     if cell is None:
@@ -102,12 +102,11 @@ def node_density(nodes: NodeStorage) -> float:
     """Density of a node set (``ops.point_density``): the value its builder left with it -- a mesh knows the share
     of the sphere it covers -- else measured once and kept with the set (a private attribute)."""
     x = torch.as_tensor(nodes.x)
-    key = ops.tensor_key(x)
     kept = nodes["_density"] if "_density" in nodes else None
-    if isinstance(kept, tuple) and kept[0] == key:
+    if isinstance(kept, tuple) and kept[0].matches(x):
         return kept[1]
     value = ops.point_density(x)
-    nodes["_density"] = (key, value)
+    nodes["_density"] = (ops.tensor_key(x), value)
     return value
 
 
@@ -201,9 +200,9 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
         mask = target_nodes[mask_attr] if mask_attr is not None else None
         # the value stays with the node set (a private attribute, removed when the graph is finished) for the other
         # cut-off builders of the graph that have these targets
-        key = ops.tensor_key(torch.as_tensor(target_nodes.x))
+        x = torch.as_tensor(target_nodes.x)
         kept = target_nodes["_reference_distance"] if "_reference_distance" in target_nodes else None
-        if mask is None and isinstance(kept, tuple) and kept[0] == key:
+        if mask is None and isinstance(kept, tuple) and kept[0].matches(x):
             return kept[1] * self.cutoff_factor
         mesh = target_nodes["_nx_graph"] if "_nx_graph" in target_nodes else None
         node_type = target_nodes["node_type"] if "node_type" in target_nodes else None
@@ -216,7 +215,7 @@ class CutOffEdges(BaseEdgeBuilder, NodeMaskingMixin):
             target_grid_reference_distance = get_grid_reference_distance(target_nodes.x, mask,
                                                                          density=node_density(target_nodes))
         if mask is None:
-            target_nodes["_reference_distance"] = (key, target_grid_reference_distance)
+            target_nodes["_reference_distance"] = (ops.tensor_key(x), target_grid_reference_distance)
         return target_grid_reference_distance * self.cutoff_factor
 
     def prepare_node_data(self, graph: HeteroData) -> tuple[NodeStorage, NodeStorage]:

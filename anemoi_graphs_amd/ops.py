@@ -174,9 +174,23 @@ class Binning:
             current.wait_event(self.ready)
 
 
-def tensor_key(t: torch.Tensor):
-    """Identity of a tensor's contents as far as it can be told without reading them."""
-    return (t.data_ptr(), tuple(t.shape), t.dtype, str(t.device), t._version)
+class TensorStamp:
+    """What a value derived from a tensor (a binning, a reference distance, a density) remembers of it: the tensor
+    OBJECT -- held, so that its memory cannot be handed to another tensor while the value is kept -- and the
+    version counter it had.  ``matches`` is true for that very object as long as no operation of torch has written
+    to it (a write through a numpy view or ``.data`` is not counted by torch and cannot be seen)."""
+
+    __slots__ = ("ref", "version")
+
+    def __init__(self, t: torch.Tensor):
+        self.ref, self.version = t, t._version
+
+    def matches(self, t) -> bool:
+        return self.ref is t and self.version == t._version
+
+
+def tensor_key(t: torch.Tensor) -> TensorStamp:
+    return TensorStamp(t)
 
 
 _DENSITIES: dict = {}  # id(tensor) -> (weak reference, version, density): valid while that very tensor is alive and unchanged

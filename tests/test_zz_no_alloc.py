@@ -13,7 +13,7 @@ from oracle import reference_path as rp
 pytestmark = pytest.mark.gpu
 
 
-def _both(lib, x: torch.Tensor):
+def _both(lib, x: torch.Tensor, check_device_memory: bool = True):
     n = x.shape[0]
     dev = x.device
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -22,8 +22,13 @@ def _both(lib, x: torch.Tensor):
     _lib.check(lib.ag_nn_maxdist(x.data_ptr(), n, 1.0, want.data_ptr(), ws.data_ptr(), ws.numel(), stream), "ag_nn_maxdist")
     got = torch.full((), -1.0, dtype=torch.float64, device=dev)
     before = torch.cuda.memory_allocated(dev)
+    torch.cuda.synchronize(dev)
+    free_before = torch.cuda.mem_get_info(dev)[0]  # what the driver has left: sees allocations torch's counter cannot
     _lib.check(lib.ag_nn_maxdist_static(x.data_ptr(), n, got.data_ptr(), stream), "ag_nn_maxdist_static")
+    torch.cuda.synchronize(dev)
     assert torch.cuda.memory_allocated(dev) == before
+    if check_device_memory:
+        assert torch.cuda.mem_get_info(dev)[0] == free_before
     return float(got.item()), float(want.item())
 
 
@@ -35,8 +40,10 @@ def test_static_scratch_entry_point_matches_workspace_entry_point(device):
     small = torch.from_numpy(grids.random_sphere(1_000, seed=4)).to(device)
     tiny = torch.tensor([[0.1, 0.2], [0.1, 0.2], [0.3, 0.1]], dtype=torch.float32, device=device)  # a coincident pair
     # two calls in a row on the same array, the second with a smaller input; then smaller again, then larger
-    for x in (big, hidden.contiguous(), small, tiny, hidden.contiguous(), small):
-        got, want = _both(lib, x)
+    # (the first call on a device may resolve the address of the built-in array; from the second on the free
+    # memory the driver reports must not move)
+    for i, x in enumerate((big, hidden.contiguous(), small, tiny, hidden.contiguous(), small)):
+        got, want = _both(lib, x, check_device_memory=i > 0)
         assert got == want and got > 0.0, (x.shape, got, want)
     # and against the oracle (scikit-learn as the reference calls it)
     got, _ = _both(lib, small)
