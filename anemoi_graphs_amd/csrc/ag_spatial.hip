@@ -305,6 +305,15 @@ extern "C" int ag_binning_build(const float* d_pts, int64_t n, double cell, void
 #define AG_KNN_RQ 256
 #define AG_KNN_RQ_STRIDE 32
 
+// A search reads what a binning and prefix sums upstream of it wrote: cell starts, candidate lists, queues.  When
+// one of those gave up (see ag_bin_scatter_kernel, ag_chained_scan_kernel) the status word of the device is set,
+// and until the host has taken it (ag_status_take, which turns it into an error) the kernels of the searches do
+// nothing at all: whatever lies in their intermediate buffers is never followed.  Their outputs are then
+// unwritten; the host discards them with the error.
+__device__ __forceinline__ bool ag_aborted(const int* status) {
+  return status != nullptr && __builtin_nontemporal_load(status) != 0;
+}
+
 struct AgKnnArgs {
   AgGrid sgrid;              // source grid
   AgGrid tgrid;              // target grid: same bands, `tmult` times the longitude cells
@@ -348,6 +357,7 @@ struct AgKnnArgs {
   unsigned long long* max_bits;  // reference-distance mode: running max of rdist (uint64 bits)
   long long* stats;          // [4]
   AgKnnArgs* device_copy;    // this structure in device memory, written by the window kernel (see AgKnnHot)
+  const int* abort;          // the status word of the device (see ag_aborted)
 };
 
 // What a wave of stage 1 reads on its usual path.  The arguments of a kernel sit in scalar registers for its whole
@@ -376,6 +386,7 @@ struct AgKnnHot {
   int k;
   int self_query;
   float rg_chord2;
+  const int* abort;
 };
 
 // Largest candidate list that is re-ranked in float64 by one thread (ag_knn_resolve_kernel, registers
@@ -453,6 +464,7 @@ struct __attribute__((aligned(32))) AgWindow {
 // grid puts thousands of targets into a polar cell and a handful into its neighbours).  One block:
 // range_off[b] = number of ranges of the bands before b.
 __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ int partial[1024];
   const int nb = a.tgrid.nb, tid = threadIdx.x;
   const int per = (nb + 1023) / 1024;
@@ -482,6 +494,7 @@ __global__ __launch_bounds__(1024) void ag_knn_band_ranges_kernel(AgKnnArgs a) {
 // one thread per descriptor: the targets of the wave and the runs of sources that cover them (stage 1
 // then starts with one load instead of a chain of dependent table look-ups per wave)
 __global__ void ag_knn_window_kernel(AgKnnArgs a, AgWindow* __restrict__ out) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the stages that follow
     a.queue_count[0] = 0;  // stage-2 queue
     a.queue_count[1] = 0;
@@ -762,6 +775,7 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
 // cost nothing), 0 = read it from the arguments.
 template <int CAP, int K>
 __global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(AgKnnHot a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ float4 tile_all[AG_WAVES_PER_BLOCK][AG_TILE];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = ag_lane();
@@ -917,6 +931,7 @@ template <int CAP, int K>
 __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g, const int* __restrict__ sstart,
                                                            const double rmax_window, AgGrid occ,
                                                            const int* __restrict__ occ_count) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   const int lane = ag_lane();
   const int k = K > 0 ? K : a.k;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -977,6 +992,7 @@ __global__ __launch_bounds__(256) void ag_knn_point_kernel(AgKnnHot a, AgGrid g,
 // ---------------------------------------------------------------------------------------------
 template <int CAP>
 __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ double sh[4];
   double my_max = 0.0;
   const int k = a.k;
@@ -1049,6 +1065,7 @@ __global__ __launch_bounds__(256) void ag_knn_resolve_kernel(AgKnnArgs a) {
 // distances of the final neighbour table (when the caller asks for them) and, for a bounded search, the removal
 // of the neighbours beyond the bound: their ids become -1, their distances +infinity
 __global__ void ag_knn_dist_kernel(AgKnnArgs a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   const int64_t total = a.nt * a.k;
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
     const int64_t t = i / a.k;
@@ -1101,6 +1118,7 @@ __device__ __forceinline__ AgPair ag_wave_min_pair(double r, int id) {
 __device__ __forceinline__ float ag_exact_outer(float t_in) { return t_in + 4.0f * ag_chord2_err(t_in) + 1.0e-11f; }
 
 __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ int set_all[4][AG_EXACT_SET];
   __shared__ double rdist_all[4][AG_EXACT_SET];
   const int lane = ag_lane();
@@ -1228,8 +1246,9 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
           const float v = __shfl(lane_min, o, 64);
           rank += (v < lane_min || (v == lane_min && o < lane)) ? 1 : 0;
         }
+        // (more neighbours wanted than there are lanes: no lane holds a k-th minimum, the bracket is the window's own)
         const unsigned long long at = __ballot(rank == k - 1);
-        t_hi = __shfl(lane_min, __ffsll(static_cast<long long>(at)) - 1, 64);
+        t_hi = at != 0ull ? __shfl(lane_min, __ffsll(static_cast<long long>(at)) - 1, 64) : 3.0e38f;
         // (fewer than k lanes met a source: every source the window is sure to hold completely)
         const float c_window = static_cast<float>(4.0 * sh * sh) * 1.000001f + 1.0e-11f;
         if (!(t_hi < c_window)) t_hi = c_window;
@@ -1374,6 +1393,22 @@ __global__ __launch_bounds__(256) void ag_knn_exact_kernel(AgKnnArgs a) {
     if (stat_targets) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), stat_targets);
     if (stat_rounds) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), stat_rounds);
   }
+}
+
+// k beyond what the lists of stage 1 hold (AG_KNN_MAX_K): every target goes straight to the wave-per-target stage,
+// whose windows double until they provably hold the k nearest (up to 256 candidates are ranked from LDS; more
+// neighbours than that are taken in k passes over the window).  The reference accepts any k up to the number of
+// sources (edges/builder.py:222-233).
+__global__ void ag_knn_queue_all_kernel(AgKnnArgs a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
+  const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
+  if (gtid == 0) {
+    a.queue_count[0] = static_cast<int>(a.nt);
+    a.queue_count[1] = 0;
+    if (a.max_bits) *a.max_bits = 0ull;
+    if (a.stats) a.stats[0] = a.stats[1] = a.stats[2] = a.stats[3] = 0;
+  }
+  for (int64_t t = gtid; t < a.nt; t += gsize) a.queue[t] = static_cast<int>(t);
 }
 
 // (Folding this into the kernel above -- the block that finishes last writes the result -- was measured: 2048 blocks
@@ -1604,6 +1639,7 @@ static void ag_launch_stage1_k(const AgKnnArgs& a, hipStream_t stream) {
   h.k = a.k;
   h.self_query = a.self_query;
   h.rg_chord2 = a.rg_chord2;
+  h.abort = a.abort;
   if (a.per_target) {
     AG_KERNEL("ag_knn_point_kernel", (ag_knn_point_kernel<CAP, K>), dim3(ag_blocks((a.nt + 63) / 64, 4, 8192)), dim3(256), stream, h, a.sgrid, a.sstart,
               a.bounded ? a.rmax_window : 0.0, a.occ_grid, a.occ_count);
@@ -1695,6 +1731,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
   a.max_bits = w.max_bits;
   a.stats = reinterpret_cast<long long*>(d_stats);
   a.device_copy = w.args_copy;
+  a.abort = ag_status_word();
   a.occ_grid = AgGrid();
   a.occ_count = nullptr;
   if (a.bounded && a.per_target) {
@@ -1719,6 +1756,17 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     AG_LAUNCH_CHECK();
   }
 
+  if (k > AG_KNN_MAX_K) {
+    AG_KERNEL("ag_knn_queue_all_kernel", ag_knn_queue_all_kernel, dim3(ag_blocks(nt, 256, 4096)), dim3(256), stream, a);
+    AG_LAUNCH_CHECK();
+    AG_KERNEL("ag_knn_exact_kernel", ag_knn_exact_kernel, dim3(2048), dim3(256), stream, a);
+    AG_LAUNCH_CHECK();
+    if (d_out_dist != nullptr || a.bounded) {
+      AG_KERNEL("ag_knn_dist_kernel", ag_knn_dist_kernel, dim3(ag_blocks(nt * k, 256, 16384)), dim3(256), stream, a);
+      AG_LAUNCH_CHECK();
+    }
+    return AG_OK;
+  }
   // (every block of the window kernel rebuilding this table in LDS, to save the one-block kernel, was measured
   // slower: 404 blocks x a prologue of dependent loads, 31.6 -> 57.6 us per build for the two searches)
   if (a.by_range) {
@@ -1766,7 +1814,7 @@ extern "C" size_t ag_knn_workspace_bytes(int64_t ns, int64_t nt, int k, double s
 extern "C" int ag_knn(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int k, double src_density,
                       double tgt_density, int32_t* d_out_src, double* d_out_dist, int64_t* d_stats, void* d_ws,
                       size_t ws_bytes, void* stream) {
-  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(k >= 1, "ag_knn: k=%d must be positive", k);
   AG_REQUIRE(ns >= k, "ag_knn: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn: node counts must fit int32");
   AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn: output too large");
@@ -1789,7 +1837,7 @@ extern "C" size_t ag_knn_binned_workspace_bytes(int64_t ns, int64_t nt, int k, d
 extern "C" int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
                              double tgt_cell, int k, double src_density, int32_t* d_out_src, double* d_out_dist,
                              int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
-  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_binned: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(k >= 1, "ag_knn_binned: k=%d must be positive", k);
   AG_REQUIRE(ns >= k, "ag_knn_binned: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 1, "ag_knn_binned: node counts out of range");
   AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn_binned: output too large");
@@ -1807,7 +1855,7 @@ extern "C" int ag_knn_binned(const float* d_src, int64_t ns, const float* d_tgt,
 extern "C" int ag_knn_edges(const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, const void* d_tgt_binning,
                             double tgt_cell, int k, double src_density, double tgt_density, int32_t* d_edge_src,
                             int32_t* d_edge_tgt, int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
-  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_edges: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(k >= 1, "ag_knn_edges: k=%d must be positive", k);
   AG_REQUIRE(ns >= k, "ag_knn_edges: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn_edges: node counts must fit int32");
   AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn_edges: output too large");
@@ -1827,7 +1875,7 @@ extern "C" int ag_knn_within(const float* d_src, int64_t ns, const float* d_tgt,
                              double src_density, double tgt_density, int32_t* d_out_src, double* d_out_dist,
                              int64_t* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
   AG_REQUIRE(max_dist > 0.0, "ag_knn_within: the distance bound must be positive (got %g)", max_dist);
-  AG_REQUIRE(k >= 1 && k <= AG_KNN_MAX_K, "ag_knn_within: k=%d outside [1, %d]", k, AG_KNN_MAX_K);
+  AG_REQUIRE(k >= 1, "ag_knn_within: k=%d must be positive", k);
   AG_REQUIRE(ns >= k, "ag_knn_within: k=%d exceeds the number of sources %lld", k, static_cast<long long>(ns));
   AG_REQUIRE(ns < (int64_t(1) << 31) && nt < (int64_t(1) << 31) && nt >= 0, "ag_knn_within: node counts must fit int32");
   AG_REQUIRE(nt * k < (int64_t(1) << 40), "ag_knn_within: output too large");
@@ -2021,6 +2069,7 @@ struct AgRadiusArgs {
   AgRadiusDesc* desc;  // [nt]
   unsigned long long* scan_state;  // state words of the scan of the counts, cleared by the window kernel
   int64_t scan_words;
+  const int* abort;  // the status word of the device (see ag_aborted)
 };
 
 // rows the count pass can keep: as long as possible within a fixed budget of entries
@@ -2036,6 +2085,14 @@ __global__ __launch_bounds__(256) void ag_radius_window_kernel(AgRadiusArgs a) {
   if (a.scan_state != nullptr)  // (count pass only) the scan that follows the count kernel starts from zeroed state
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < a.scan_words; i += int64_t(gridDim.x) * blockDim.x)
       a.scan_state[i] = 0ull;
+  if (ag_aborted(a.abort)) {
+    // (see ag_aborted)  Count pass: the counts become 0, 0, ... with -1 in front, so that their total -- which the
+    // host reads for the size of the edge list -- is negative, its sign of a failed query.
+    if (a.scan_state != nullptr)
+      for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < a.nt; t += int64_t(gridDim.x) * blockDim.x)
+        a.offsets[t] = t == 0 ? -1 : 0;
+    return;
+  }
   for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < a.nt; t += int64_t(gridDim.x) * blockDim.x) {
     const float2 tpf = a.tgt[t];
     const float3 tu = ag_unit_vec(tpf.x, tpf.y);
@@ -2335,6 +2392,7 @@ __global__ __launch_bounds__(256) void ag_radius_groups_init_kernel(AgRadiusArgs
 }
 
 __global__ void ag_radius_group_count_kernel(AgRadiusArgs a, AgRadiusGroups gr) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < a.nt; t += int64_t(gridDim.x) * blockDim.x) {
     const float2 p = a.tgt[t];
     const int band = ag_band_of(a.grid, static_cast<double>(p.x));
@@ -2367,7 +2425,7 @@ __global__ void ag_radius_group_count_kernel(AgRadiusArgs a, AgRadiusGroups gr) 
 // of the query become 0, 0, ... with -1 in front, and their total -- negative -- is what the caller's check of the
 // edge count reports.
 __global__ __launch_bounds__(256) void ag_radius_group_desc_kernel(AgRadiusArgs a, AgRadiusGroups gr) {
-  const bool failed = gr.gcount[gr.ngroups] != static_cast<int>(a.nt);
+  const bool failed = ag_aborted(a.abort) || gr.gcount[gr.ngroups] != static_cast<int>(a.nt);
   const AgGrid& grid = a.grid;
   for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < a.nt; t += int64_t(gridDim.x) * blockDim.x) {
     if (failed) {
@@ -2465,9 +2523,11 @@ struct AgRadiusHot {
   float c_in, c_out;
   int stash_cap;
   int run;              // consecutive blocks' worth of positions a die takes at a time
+  const int* abort;
 };
 
 __global__ __launch_bounds__(256) void ag_radius_count_kernel(AgRadiusHot a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ __attribute__((aligned(16))) int row_all[4][AG_STASH_MAX + 4];
   __shared__ int pending_all[4][AG_RC_PENDING];
   const int lane = ag_lane();
@@ -2589,6 +2649,7 @@ __global__ __launch_bounds__(256) void ag_radius_count_kernel(AgRadiusHot a) {
 // targets; its threads stride over the block's contiguous piece of the output and find their row
 // by binary search among the group's offsets (LDS).
 __global__ __launch_bounds__(256) void ag_radius_copy_kernel(AgRadiusArgs a) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ int64_t off[AG_COPY_GROUP + 1];
   for (int64_t t0 = int64_t(blockIdx.x) * AG_COPY_GROUP; t0 < a.nt; t0 += int64_t(gridDim.x) * AG_COPY_GROUP) {
     const int n = static_cast<int>(min(int64_t(AG_COPY_GROUP), a.nt - t0));
@@ -2616,10 +2677,15 @@ __global__ __launch_bounds__(256) void ag_radius_copy_kernel(AgRadiusArgs a) {
 // [begin, end) for the segmented sort -- empty for the rows the copy kernel already wrote.
 __global__ __launch_bounds__(256) void ag_radius_long_kernel(AgRadiusArgs a, uint32_t* __restrict__ seg_begin,
                                                              uint32_t* __restrict__ seg_end) {
+  const bool aborted = ag_aborted(a.abort);  // (see ag_aborted: no row is searched, and the sort is left nothing to do)
   const int lane = ag_lane();
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
   for (int64_t t = wave_global; t < a.nt; t += nwaves) {
+    if (aborted) {
+      if (lane == 0) seg_begin[t] = seg_end[t] = 0u;
+      continue;
+    }
     const int64_t base_out = a.offsets[t];
     const int64_t n_row = a.offsets[t + 1] - base_out;
     const bool is_long = n_row > a.stash_cap;
@@ -2634,6 +2700,7 @@ __global__ __launch_bounds__(256) void ag_radius_long_kernel(AgRadiusArgs a, uin
 // after the segmented sort: long rows get their sorted sources (when the sort left them in the
 // target column) and their target ids
 __global__ __launch_bounds__(256) void ag_radius_long_finish_kernel(AgRadiusArgs a, int sorted_in_tgt) {
+  if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   const int lane = ag_lane();
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -2797,6 +2864,7 @@ static int ag_radius_args(const float* d_src, const float* d_tgt, int64_t nt, do
   a->desc = w.desc;
   a->scan_state = nullptr;
   a->scan_words = 0;
+  a->abort = ag_status_word();
   a->radius = radius < AG_PI ? radius : AG_PI;
   const double s = sin(0.5 * radius);
   a->rthr = s * s;
@@ -2894,6 +2962,7 @@ static int ag_radius_count_impl(const float* d_src, int64_t ns, const AgKeptBinn
     hot.c_in = a.c_in;
     hot.c_out = a.c_out;
     hot.stash_cap = a.stash_cap;
+    hot.abort = a.abort;
     // A wave per position and sweep, a few sweeps; the grid a multiple of 8 x AG_RC_RUN blocks (see the kernel).
     hot.run = AG_RC_RUN;
     const int unit = 8 * AG_RC_RUN;

@@ -28,6 +28,58 @@ def device_of(*tensors: torch.Tensor) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+# ---------------------------------------------------------------------------------------------------
+# Device mirrors of host tensors.  With graph tensors on the host (the package's default, as in the reference) the
+# same tensors cross the link again and again: the data coordinates once per builder and attribute that reads them,
+# every edge list down to the host and up again for its attributes.  A host tensor that was uploaded, or that is the
+# host copy of a device result (``utils.to_host``), keeps its device twin here -- found again by the identity of the
+# tensor object and its version counter (any write torch knows of invalidates it), dropped when the host tensor
+# dies, and evicted oldest-first beyond a budget of device memory.
+# ---------------------------------------------------------------------------------------------------
+_MIRROR_BUDGET = 4 << 30  # bytes of device memory the mirrors may hold
+_MIRRORS: dict = {}       # (id(host tensor), device index, dtype) -> (weak reference, version, device tensor)
+
+
+def _mirror_drop(key) -> None:
+    _MIRRORS.pop(key, None)
+
+
+def mirror_put(host: torch.Tensor, twin: torch.Tensor) -> None:
+    """Remember ``twin`` (a device tensor with the contents of ``host``) as the device side of ``host``."""
+    nbytes = twin.numel() * twin.element_size()
+    if nbytes > _MIRROR_BUDGET // 2 or twin.dtype != host.dtype or tuple(twin.shape) != tuple(host.shape):
+        return
+    index = twin.device.index if twin.device.index is not None else torch.cuda.current_device()
+    key = (id(host), index, twin.dtype)
+    held = sum(v[2].numel() * v[2].element_size() for v in _MIRRORS.values())
+    for old in list(_MIRRORS):  # (insertion order: oldest first)
+        if held + nbytes <= _MIRROR_BUDGET and len(_MIRRORS) < 256:
+            break
+        held -= _MIRRORS[old][2].numel() * _MIRRORS[old][2].element_size()
+        del _MIRRORS[old]
+    _MIRRORS[key] = (weakref.ref(host, lambda _ref, key=key: _mirror_drop(key)), host._version, twin)
+
+
+def _mirror_get(host: torch.Tensor, device: torch.device, dtype: torch.dtype):
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    found = _MIRRORS.get((id(host), index, dtype))
+    if found is not None and found[0]() is host and found[1] == host._version:
+        return found[2]
+    return None
+
+
+def as_device(x, device: torch.device, dtype: torch.dtype) -> torch.Tensor:
+    """Contiguous tensor of ``dtype`` on ``device`` with the contents of ``x``; a host tensor's upload is kept as
+    its mirror, and found again the next time."""
+    if isinstance(x, torch.Tensor) and x.device.type == "cpu" and x.dtype == dtype:
+        twin = _mirror_get(x, device, dtype)
+        if twin is None:
+            twin = x.to(device=device).contiguous()
+            mirror_put(x, twin)
+        return twin
+    return torch.as_tensor(x).to(device=device, dtype=dtype).contiguous()
+
+
 def coords(x, device: torch.device) -> torch.Tensor:
     """float32 contiguous [N,2] copy/view of node coordinates on ``device``."""
     if (isinstance(x, torch.Tensor) and x.dtype is torch.float32 and x.device == device and x.ndim == 2
@@ -36,7 +88,7 @@ def coords(x, device: torch.device) -> torch.Tensor:
     t = torch.as_tensor(x)
     if t.ndim != 2 or t.shape[1] != 2:
         raise ValueError(f"coordinates must have shape [N, 2], got {tuple(t.shape)}")
-    return t.to(device=device, dtype=torch.float32).contiguous()
+    return as_device(t, device, torch.float32)
 
 
 _NO_SWITCH = contextlib.nullcontext()
@@ -624,7 +676,7 @@ def edge_attrs(src_x: torch.Tensor, tgt_x: torch.Tensor, edge_index: torch.Tenso
     lib = _lib.load()
     dev = device_of(edge_index, src_x, tgt_x)
     src_x, tgt_x = coords(src_x, dev), coords(tgt_x, dev)
-    e = torch.as_tensor(edge_index).to(device=dev, dtype=torch.int32).contiguous()
+    e = as_device(edge_index, dev, torch.int32)
     if e.ndim != 2 or e.shape[0] != 2:
         raise ValueError(f"edge_index must have shape [2, E], got {tuple(e.shape)}")
     num_edges = e.shape[1]
@@ -743,6 +795,8 @@ def voronoi_areas(x: torch.Tensor, neighbours: int = VORONOI_NEIGHBOURS, return_
     k = min(int(neighbours), n, 64)
     with _on(dev):
         nbr = knn(x, x, k)
+        check_status(dev)  # (the cells follow these ids: a search that failed must not get that far; this path
+        #                     synchronises with the device after every pass anyway)
         area = torch.empty(n, dtype=torch.float64, device=dev)
         reach = torch.empty(n, dtype=torch.float64, device=dev)
         _lib.check(lib.ag_voronoi_areas_knn(_ptr(x), n, _ptr(nbr), k, _ptr(area), _ptr(reach), _stream(dev)),
@@ -773,6 +827,7 @@ def voronoi_areas(x: torch.Tensor, neighbours: int = VORONOI_NEIGHBOURS, return_
                 radius = min(base * (2.0 ** o) * (1.0 + 1.0e-12), math.pi)
                 ids = sel.to(torch.int32).contiguous()
                 offsets, rows = radius_rows(x, x[sel].contiguous(), radius)
+                check_status(dev)
                 _lib.check(
                     lib.ag_voronoi_areas_rows(_ptr(x), n, _ptr(ids), ids.numel(), _ptr(offsets), _ptr(rows), radius,
                                               _ptr(area), _ptr(reach), _stream(dev)),

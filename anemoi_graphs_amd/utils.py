@@ -16,10 +16,15 @@ def to_host(t: torch.Tensor) -> torch.Tensor:
     if not t.is_cuda:
         return t
     if t.numel() * t.element_size() < _PINNED_FROM:
-        return t.cpu()
-    out = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
-    out.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
+        out = t.cpu()
+    else:
+        out = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+        out.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+    # the device tensor stays on as the mirror of its host copy: an edge list that goes to the host here is read on
+    # the device again by the attributes of its edge set
+    if t.is_contiguous():
+        ops.mirror_put(out, t)
     return out
 
 

@@ -67,7 +67,8 @@ int ag_debug_poison_scans(int on);
  * ties are broken towards the lower source id.  d_out_dist (nullable) receives the distance
  * 2*asin(sqrt(rdist)) in radians.  d_stats (nullable, int64[4]) receives: [0] targets resolved
  * by the float64 wave-per-target path, [1] passes of that path beyond the first window.
- * Requires 1 <= k <= ns and k <= AG_KNN_MAX_K.
+ * Requires 1 <= k <= ns.  Up to AG_KNN_MAX_K neighbours the targets share tiles of sources in a first stage; beyond
+ * that every target is searched on its own by a wavefront (any k: the reference has no limit either, edges/builder.py:222-233).
  *
  * src_density, tgt_density (no counterpart in the reference, whose ball tree adapts to its points by itself):
  * how many times more nodes per steradian a set has, where it has nodes, than the same number of nodes spread

@@ -112,3 +112,7 @@ def test_single_launch_scan_and_its_bounded_wait(device):
     _lib.check(lib.ag_scan_i32(values.data_ptr(), out.data_ptr(), n, state.data_ptr(), 16, stream), "ag_scan_i32")
     torch.cuda.synchronize(device)
     assert int(state[3]) == 1  # the error word
+    # ... and the status word of the device, which the host reads (and clears) where it synchronises
+    status = ctypes.c_int(0)
+    _lib.check(lib.ag_status_take(ctypes.byref(status)), "ag_status_take")
+    assert status.value == 1

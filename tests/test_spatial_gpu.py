@@ -36,6 +36,20 @@ def test_knn_random(device, k):
     print("knn random", k, res["tie_rows"], stats)
 
 
+@pytest.mark.parametrize("ns,nt,k", [(300, 500, 100), (300, 500, 300), (3000, 2000, 65), (3000, 2000, 200),
+                                      (400, 100, 300), (5000, 300, 1000)])
+def test_knn_more_neighbours_than_the_first_stage_holds(device, ns, nt, k):
+    """k beyond 64 -- the reference takes any positive integer up to the number of sources
+    (edges/builder.py:222-233) -- up to every source there is: all targets go through the wave-per-target stage
+    (k <= 256 ranked from LDS, more in k passes).  Rows and distances equal scikit-learn's."""
+    src, tgt = grids.random_sphere(ns, seed=41), grids.random_sphere(nt, seed=42)
+    res, stats = _knn_case(src, tgt, k, device)
+    assert res["tie_rows"] == 0 and stats[0] == nt
+    # and through the builder, with the edge list written by the search
+    e = ops.knn_edges(torch.from_numpy(src).to(device), torch.from_numpy(tgt).to(device), k).cpu().numpy()
+    assert np.array_equal(e, rp.knn_edges(src, tgt, k))
+
+
 def test_knn_regular_grid_with_ties(device):
     # poles (coincident points), exact symmetric ties
     src, tgt = grids.fibonacci_sphere(642), grids.regular(2.0)
