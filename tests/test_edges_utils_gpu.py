@@ -116,3 +116,21 @@ def test_single_launch_scan_and_its_bounded_wait(device):
     status = ctypes.c_int(0)
     _lib.check(lib.ag_status_take(ctypes.byref(status)), "ag_status_take")
     assert status.value == 1
+
+
+def test_large_results_reach_the_host_whole(device):
+    """Results of tens of megabytes travel as several pieces on streams of their own: the host tensor holds every
+    element, also when the work that makes the tensor was queued just before the copy."""
+    from anemoi_graphs_amd.utils import to_host
+
+    torch.cuda.set_device(device)
+    for shape, dtype in (((2, 3_000_001), torch.int64), ((5_000_003, 2), torch.float32), ((4_194_304,), torch.float32)):
+        n = int(np.prod(shape))
+        for _ in range(3):
+            base = torch.arange(n, device=device, dtype=torch.float32)
+            t = (base * 3.0 + 1.0).to(dtype).reshape(shape)  # queued, not waited for
+            host = to_host(t)
+            assert host.device.type == "cpu" and host.shape == t.shape and host.dtype == dtype
+            assert torch.equal(host, t.cpu())
+    view = torch.arange(12_000_000, device=device, dtype=torch.float32).reshape(2, -1).t()  # not contiguous
+    assert torch.equal(to_host(view), view.cpu())
