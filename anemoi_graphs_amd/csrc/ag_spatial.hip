@@ -92,30 +92,73 @@ __device__ __forceinline__ int ag_band_of_cell(const AgGrid& g, int c) {
   return lo;
 }
 
-__global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n, int* __restrict__ cell_of,
-                                    int* __restrict__ slot_of, int* __restrict__ count) {
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    const float2 p = pts[i];
-    const int c = ag_cell_of(g, static_cast<double>(p.x), static_cast<double>(p.y));
-    cell_of[i] = c;
+// Which points a block takes: tiles of 256 * U consecutive points, U per thread (the thread's points are 256 apart,
+// every wavefront reads and writes whole lines).  U = 4 for large sets: the four loads of a thread, its four
+// counter updates and its four stores are in flight together, and a kernel that waits for memory most of its time
+// gets four times the bytes per wait.
+// Blocks are handed to the eight dies in turn (block b to die b % 8), and every die has a second-level cache of
+// its own.  Points that follow each other in the caller's order (the rows of a grid) fall into the same cells, a
+// few points each: the record lines of those cells are completed by several blocks, and they are completed in ONE
+// cache, and leave it whole, when those blocks run on the same die.  So the tiles are dealt out in chunks: `chunk`
+// consecutive tiles to one die, the next chunk to the next die.  The launch has a multiple of eight blocks, and
+// every block walks b, b + gridDim, ... (the same die every time).
+struct AgTileDeal {
+  int64_t ntiles_padded;  // a multiple of 8 * chunk; tiles beyond the last point hold nothing
+  int chunk;
+  int unroll;             // U: 1, 4 or 8
+};
+static AgTileDeal ag_tile_deal(int64_t n) {
+  const int unroll = n >= (int64_t(1) << 26) ? 8 : (n >= (int64_t(1) << 22) ? 4 : 1);
+  const int64_t per_tile = 256 * unroll, ntiles = (n + per_tile - 1) / per_tile;
+  int chunk = 1;
+  while (chunk < 1024 && int64_t(chunk) * 2 * 64 <= ntiles) chunk *= 2;  // (at least 8 rounds over the dies)
+  const int64_t round = 8 * int64_t(chunk);
+  return AgTileDeal{(ntiles + round - 1) / round * round, chunk, unroll};
+}
+static int ag_tile_blocks(const AgTileDeal& d) { return static_cast<int>(d.ntiles_padded < 16384 ? d.ntiles_padded : 16384); }
+__device__ __forceinline__ int64_t ag_dealt_tile(int64_t vb, int chunk) {
+  const int64_t round = 8 * int64_t(chunk), r = vb % round;
+  return ((vb / round) * 8 + (r & 7)) * chunk + (r >> 3);
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n,
+                                                           int* __restrict__ cell_of, int* __restrict__ slot_of,
+                                                           int* __restrict__ count, AgTileDeal deal) {
+  const int lane = ag_lane();
+  for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
+    const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
+    if (first - threadIdx.x >= n) continue;  // (the whole block)
+    float2 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = pts[min(first + u * 256, n - 1)];
     // Neighbouring points usually share a cell.  A run = consecutive lanes with the same cell; the
     // first lane of every run takes the run's slots with one atomic (all runs of the wave in the
-    // same instruction) and hands the base to the lanes behind it.  Lanes past the end of the
-    // array are the highest lanes of the last wave, so an active lane's predecessor is active.
-    const int lane = ag_lane();
-    const int prev = __shfl_up(c, 1, 64);
-    const bool head = (lane == 0) || (prev != c);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long active = __ballot(1);
-    const int my_head = 63 - __clzll(static_cast<long long>(heads & (~0ull >> (63 - lane))));
-    const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
-    const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1)
-                              : (64 - __clzll(static_cast<long long>(active)));
-    int base = 0;
-    if (head) base = atomicAdd(&count[c], run_end - lane);
-    base = __shfl(base, my_head, 64);
-    const int slot = base + (lane - my_head);
-    slot_of[i] = slot;
+    // same instruction) and hands the base to the lanes behind it.  Lanes past the end of the array (the highest
+    // lanes of the last wave) carry the cell -1: a run of their own that counts nothing.
+    int c[U], base[U], my_head[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool on = first + u * 256 < n;
+      c[u] = on ? ag_cell_of(g, static_cast<double>(p[u].x), static_cast<double>(p[u].y)) : -1;
+      const int prev = __shfl_up(c[u], 1, 64);
+      const bool head = (lane == 0) || (prev != c[u]);
+      const unsigned long long heads = __ballot(head);
+      my_head[u] = 63 - __clzll(static_cast<long long>(heads & (~0ull >> (63 - lane))));
+      const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
+      const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1) : 64;
+      base[u] = 0;
+      if (head && on) base[u] = atomicAdd(&count[c[u]], run_end - lane);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int start = __shfl(base[u], my_head[u], 64);
+      const int64_t i = first + u * 256;
+      if (i < n) {
+        cell_of[i] = c[u];
+        slot_of[i] = start + (lane - my_head[u]);
+      }
+    }
   }
 }
 
@@ -125,30 +168,64 @@ __global__ void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, in
 // but sound: every cell without points, the records and ids in the points' own order (all initialised, all ids
 // valid), and the library's status word set, which the host turns into an error at its next synchronisation.
 #define AG_STATUS_BINNING_FAILED 2
-__global__ void ag_bin_scatter_kernel(const float2* __restrict__ pts, int64_t n, const int* __restrict__ cell_of,
-                                      const int* __restrict__ slot_of, int* __restrict__ cell_start, int64_t ncells,
-                                      float4* __restrict__ out_pts, int* __restrict__ out_ids, int* __restrict__ status) {
+template <int U>
+__global__ __launch_bounds__(256) void ag_bin_scatter_kernel(int64_t n, const int* __restrict__ cell_of,
+                                                             const int* __restrict__ slot_of,
+                                                             int* __restrict__ cell_start, int64_t ncells,
+                                                             int* __restrict__ out_ids, int* __restrict__ status,
+                                                             AgTileDeal deal) {
   if (cell_start[ncells] != static_cast<int>(n)) {  // (the same for every thread of the launch: nobody writes that word)
     const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
     for (int64_t c = gtid; c < ncells; c += gsize) cell_start[c] = 0;
-    for (int64_t i = gtid; i < n; i += gsize) {
-      out_ids[i] = static_cast<int>(i);
-      if (out_pts != nullptr) {
-        const float2 p = pts[i];
-        const float3 u = ag_unit_vec(p.x, p.y);
-        out_pts[i] = make_float4(u.x, u.y, u.z, __int_as_float(static_cast<int>(i)));
-      }
-    }
+    for (int64_t i = gtid; i < n; i += gsize) out_ids[i] = static_cast<int>(i);
     if (gtid == 0 && status != nullptr) *status = AG_STATUS_BINNING_FAILED;
     return;
   }
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    const int pos = cell_start[cell_of[i]] + slot_of[i];
-    out_ids[pos] = static_cast<int>(i);
-    if (out_pts != nullptr) {
-      const float2 p = pts[i];
-      const float3 u = ag_unit_vec(p.x, p.y);
-      out_pts[pos] = make_float4(u.x, u.y, u.z, __int_as_float(static_cast<int>(i)));
+  // Only the ids are scattered (4 bytes a point: the lines of a cell are completed by the blocks of several rows of
+  // the caller's grid, and lines that leave the cache half written are what a scatter pays for); the 16-byte
+  // records are then written in their own order, whole lines at a time, by ag_bin_records_kernel.
+  for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
+    const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
+    if (first - threadIdx.x >= n) continue;  // (the whole block)
+    int c[U], slot[U], start[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // (lanes past the end read the last point again and write nothing)
+      const int64_t i = min(first + u * 256, n - 1);
+      c[u] = cell_of[i];
+      slot[u] = slot_of[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) start[u] = cell_start[c[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = first + u * 256;
+      if (i < n) out_ids[start[u] + slot[u]] = static_cast<int>(i);
+    }
+  }
+}
+
+// The records of a binning, in the order of the binning: the unit vector of the point every id names, and the id.
+// (The points of a cell come from a few rows of the caller's grid, a short run of neighbours from each: the reads
+// are served by the caches, the writes are whole lines.)  After a binning that failed the ids are the identity.
+template <int U>
+__global__ __launch_bounds__(256) void ag_bin_records_kernel(const float2* __restrict__ pts, int64_t n,
+                                                             const int* __restrict__ ids, float4* __restrict__ out_pts,
+                                                             AgTileDeal deal) {
+  for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
+    const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
+    if (first - threadIdx.x >= n) continue;  // (the whole block)
+    int id[U];
+    float2 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = ids[min(first + u * 256, n - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = pts[min(max(id[u], 0), static_cast<int>(n - 1))];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pos = first + u * 256;
+      if (pos >= n) continue;
+      const float3 v = ag_unit_vec(p[u].x, p[u].y);
+      out_pts[pos] = make_float4(v.x, v.y, v.z, __int_as_float(id[u]));
     }
   }
 }
@@ -233,16 +310,32 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
             ag_debug_scans_poisoned() ? 0x40000000ull : 0ull);  // (poisoned: every tile draws a ticket beyond the last tile)
   AG_LAUNCH_CHECK();
   int rc = AG_OK;
-  const int blocks = ag_blocks(n, 256, 16384);
-  AG_KERNEL("ag_bin_count_kernel", ag_bin_count_kernel, dim3(blocks), dim3(256), stream, out->grid,
-            reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start);
+  const AgTileDeal deal = ag_tile_deal(n);
+  const int blocks = ag_tile_blocks(deal);  // (a multiple of 8, blocks of 256 threads: see ag_dealt_tile)
+#define AG_BIN_LAUNCH(name, kernel, ...)                                                         \
+  do {                                                                                          \
+    if (deal.unroll == 8) {                                                                     \
+      AG_KERNEL(name, kernel<8>, dim3(blocks), dim3(256), stream, __VA_ARGS__);                 \
+    } else if (deal.unroll == 4) {                                                              \
+      AG_KERNEL(name, kernel<4>, dim3(blocks), dim3(256), stream, __VA_ARGS__);                 \
+    } else {                                                                                    \
+      AG_KERNEL(name, kernel<1>, dim3(blocks), dim3(256), stream, __VA_ARGS__);                 \
+    }                                                                                           \
+  } while (0)
+  AG_BIN_LAUNCH("ag_bin_count_kernel", ag_bin_count_kernel, out->grid, reinterpret_cast<const float2*>(d_pts), n,
+                c.cell_of, c.slot_of, c.cell_start, deal);
   AG_LAUNCH_CHECK();
   rc = ag_chained_scan_i32(c.cell_start, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> [ncells_ub]
   if (rc) return rc;
-  AG_KERNEL("ag_bin_scatter_kernel", ag_bin_scatter_kernel, dim3(blocks), dim3(256), stream,
-            reinterpret_cast<const float2*>(d_pts), n, c.cell_of, c.slot_of, c.cell_start, ncells_ub, c.pts, c.ids,
-            ag_status_word());
+  AG_BIN_LAUNCH("ag_bin_scatter_kernel", ag_bin_scatter_kernel, n, c.cell_of, c.slot_of, c.cell_start, ncells_ub, c.ids,
+                ag_status_word(), deal);
   AG_LAUNCH_CHECK();
+  if (c.pts != nullptr) {
+    AG_BIN_LAUNCH("ag_bin_records_kernel", ag_bin_records_kernel, reinterpret_cast<const float2*>(d_pts), n, c.ids, c.pts,
+                  deal);
+    AG_LAUNCH_CHECK();
+  }
+#undef AG_BIN_LAUNCH
   return AG_OK;
 }
 
