@@ -121,10 +121,31 @@ __device__ __forceinline__ int64_t ag_dealt_tile(int64_t vb, int chunk) {
   return ((vb / round) * 8 + (r & 7)) * chunk + (r >> 3);
 }
 
+// Runs of a wavefront: consecutive lanes with the same cell.  Neighbouring points usually share a cell, so the first
+// lane of every run speaks for the run (all runs of the wave in the same instruction).  Lanes past the end of the
+// array (the highest lanes of the last wave) carry the cell -1: a run of their own that takes part in nothing.
+struct AgLaneRun {
+  bool head;    // this lane is the first of its run
+  int first;    // lane of the head of this lane's run
+  int length;   // (heads only) lanes in the run
+};
+__device__ __forceinline__ AgLaneRun ag_lane_run(int cell, int lane) {
+  const int prev = __shfl_up(cell, 1, 64);
+  AgLaneRun r;
+  r.head = (lane == 0) || (prev != cell);
+  const unsigned long long heads = __ballot(r.head);
+  r.first = 63 - __clzll(static_cast<long long>(heads & (~0ull >> (63 - lane))));
+  const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
+  r.length = (above ? (__ffsll(static_cast<long long>(above)) - 1) : 64) - lane;
+  return r;
+}
+
+// The cell of every point, and how many points every cell holds: counter[1 + c] for cell c (the array is read one
+// entry further on, as the cell starts, once ag_bin_scatter_kernel has gone over it).
 template <int U>
 __global__ __launch_bounds__(256) void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n,
-                                                           int* __restrict__ cell_of, int* __restrict__ slot_of,
-                                                           int* __restrict__ count, AgTileDeal deal) {
+                                                           int* __restrict__ cell_of, int* __restrict__ counter,
+                                                           AgTileDeal deal) {
   const int lane = ag_lane();
   for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
     const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
@@ -132,74 +153,66 @@ __global__ __launch_bounds__(256) void ag_bin_count_kernel(AgGrid g, const float
     float2 p[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) p[u] = pts[min(first + u * 256, n - 1)];
-    // Neighbouring points usually share a cell.  A run = consecutive lanes with the same cell; the
-    // first lane of every run takes the run's slots with one atomic (all runs of the wave in the
-    // same instruction) and hands the base to the lanes behind it.  Lanes past the end of the array (the highest
-    // lanes of the last wave) carry the cell -1: a run of their own that counts nothing.
-    int c[U], base[U], my_head[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool on = first + u * 256 < n;
-      c[u] = on ? ag_cell_of(g, static_cast<double>(p[u].x), static_cast<double>(p[u].y)) : -1;
-      const int prev = __shfl_up(c[u], 1, 64);
-      const bool head = (lane == 0) || (prev != c[u]);
-      const unsigned long long heads = __ballot(head);
-      my_head[u] = 63 - __clzll(static_cast<long long>(heads & (~0ull >> (63 - lane))));
-      const unsigned long long above = (lane == 63) ? 0ull : ((heads >> (lane + 1)) << (lane + 1));
-      const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1) : 64;
-      base[u] = 0;
-      if (head && on) base[u] = atomicAdd(&count[c[u]], run_end - lane);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int start = __shfl(base[u], my_head[u], 64);
       const int64_t i = first + u * 256;
-      if (i < n) {
-        cell_of[i] = c[u];
-        slot_of[i] = start + (lane - my_head[u]);
-      }
+      const bool on = i < n;
+      const int c = on ? ag_cell_of(g, static_cast<double>(p[u].x), static_cast<double>(p[u].y)) : -1;
+      const AgLaneRun run = ag_lane_run(c, lane);
+      if (run.head && on) atomicAdd(&counter[1 + c], run.length);  // (nobody waits for the old value)
+      if (on) cell_of[i] = c;
     }
   }
 }
 
-// The scan of the cell counts leaves their total in cell_start[ncells]: every point was counted once, so it is n.
-// Anything else means the scan gave up (state words that were not clear) and the cell starts cannot be trusted --
-// some records would never be written, and the searches follow the ids they hold.  The binning is then left EMPTY
-// but sound: every cell without points, the records and ids in the points' own order (all initialised, all ids
-// valid), and the library's status word set, which the host turns into an error at its next synchronisation.
+// The scan of the counters leaves the start of cell c in cursor[1 + c] and their total in cursor[1 + ncells]: every
+// point was counted once, so it is n.  The points then take their places: the head of a run moves the cursor of its
+// cell forward by the run, and the run's ids go where the cursor stood.  When every point is placed the cursor of
+// cell c stands at the start of cell c + 1: read from entry 0 (which nobody touched: zero) the array IS the cell
+// starts, entry ncells the total.
+// A total other than n means that the scan gave up (state words that were not clear) and the starts cannot be
+// trusted -- some places would never be written, and the searches follow the ids they hold.  The binning is then
+// left EMPTY but sound: every cell without points, the ids (and with them the records) in the points' own order
+// (all initialised, all ids valid), and the library's status word set, which the host turns into an error at its
+// next synchronisation.
+// Only the ids are scattered (4 bytes a point: the lines of a cell are completed by the blocks of several rows of
+// the caller's grid, and lines that leave the cache half written are what a scatter pays for); the 16-byte records
+// are then written in their own order, whole lines at a time, by ag_bin_records_kernel.
 #define AG_STATUS_BINNING_FAILED 2
 template <int U>
 __global__ __launch_bounds__(256) void ag_bin_scatter_kernel(int64_t n, const int* __restrict__ cell_of,
-                                                             const int* __restrict__ slot_of,
-                                                             int* __restrict__ cell_start, int64_t ncells,
+                                                             int* __restrict__ cursor, int64_t ncells,
                                                              int* __restrict__ out_ids, int* __restrict__ status,
                                                              AgTileDeal deal) {
-  if (cell_start[ncells] != static_cast<int>(n)) {  // (the same for every thread of the launch: nobody writes that word)
+  if (cursor[1 + ncells] != static_cast<int>(n)) {  // (the same for every thread of the launch: nobody writes that word)
     const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t c = gtid; c < ncells; c += gsize) cell_start[c] = 0;
+    for (int64_t c = gtid; c <= ncells; c += gsize) cursor[c] = 0;
     for (int64_t i = gtid; i < n; i += gsize) out_ids[i] = static_cast<int>(i);
     if (gtid == 0 && status != nullptr) *status = AG_STATUS_BINNING_FAILED;
     return;
   }
-  // Only the ids are scattered (4 bytes a point: the lines of a cell are completed by the blocks of several rows of
-  // the caller's grid, and lines that leave the cache half written are what a scatter pays for); the 16-byte
-  // records are then written in their own order, whole lines at a time, by ag_bin_records_kernel.
+  const int lane = ag_lane();
   for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
     const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
     if (first - threadIdx.x >= n) continue;  // (the whole block)
-    int c[U], slot[U], start[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {  // (lanes past the end read the last point again and write nothing)
-      const int64_t i = min(first + u * 256, n - 1);
-      c[u] = cell_of[i];
-      slot[u] = slot_of[i];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) start[u] = cell_start[c[u]];
+    int c[U], base[U], head_lane[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = first + u * 256;
-      if (i < n) out_ids[start[u] + slot[u]] = static_cast<int>(i);
+      c[u] = i < n ? cell_of[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const AgLaneRun run = ag_lane_run(c[u], lane);
+      head_lane[u] = run.first;
+      base[u] = 0;
+      if (run.head && c[u] >= 0) base[u] = atomicAdd(&cursor[1 + c[u]], run.length);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int place = __shfl(base[u], head_lane[u], 64) + (lane - head_lane[u]);
+      const int64_t i = first + u * 256;
+      if (i < n) out_ids[place] = static_cast<int>(i);
     }
   }
 }
@@ -261,7 +274,7 @@ static int64_t ag_grid_cells_ub(int nb, int mult = 1) {
 }
 
 struct AgBinCarve {
-  int *ncols, *off, *cell_start, *cell_of, *slot_of, *ids;
+  int *ncols, *off, *cell_start, *cell_of, *ids;
   double* win;
   float4* pts;
   unsigned long long* scan_state;
@@ -273,9 +286,10 @@ static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool
   c->ncols = ws.take<int>(nb_reserve);
   c->off = ws.take<int>(nb_reserve + 1);
   c->win = ws.take<double>(nb_reserve);
-  c->cell_start = ws.take<int>(cells);
+  // (entry 1, where the counters and the scan begin, on a 16-byte boundary: the scan moves 16-byte pieces then)
+  int* const counters = ws.take<int>(cells + 4);
+  c->cell_start = counters ? counters + 3 : nullptr;
   c->cell_of = ws.take<int>(n);
-  c->slot_of = ws.take<int>(n);
   c->ids = ws.take<int>(n);
   c->scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i32(cells));
   c->scan_state = ws.take<unsigned long long>(c->scan_words);
@@ -306,7 +320,7 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   ag_bin_describe(c, n, nb, mult, out);
   const int64_t ncells_ub = out->ncells_ub;
   AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(ncells_ub + 1, 4096, 256)), dim3(1024), stream,
-            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1, c.scan_state, c.scan_words,
+            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 2, c.scan_state, c.scan_words,
             ag_debug_scans_poisoned() ? 0x40000000ull : 0ull);  // (poisoned: every tile draws a ticket beyond the last tile)
   AG_LAUNCH_CHECK();
   int rc = AG_OK;
@@ -323,11 +337,11 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
     }                                                                                           \
   } while (0)
   AG_BIN_LAUNCH("ag_bin_count_kernel", ag_bin_count_kernel, out->grid, reinterpret_cast<const float2*>(d_pts), n,
-                c.cell_of, c.slot_of, c.cell_start, deal);
+                c.cell_of, c.cell_start, deal);
   AG_LAUNCH_CHECK();
-  rc = ag_chained_scan_i32(c.cell_start, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> [ncells_ub]
+  rc = ag_chained_scan_i32(c.cell_start + 1, c.cell_start + 1, ncells_ub, c.scan_state, stream);  // total -> [1 + ncells_ub]
   if (rc) return rc;
-  AG_BIN_LAUNCH("ag_bin_scatter_kernel", ag_bin_scatter_kernel, n, c.cell_of, c.slot_of, c.cell_start, ncells_ub, c.ids,
+  AG_BIN_LAUNCH("ag_bin_scatter_kernel", ag_bin_scatter_kernel, n, c.cell_of, c.cell_start, ncells_ub, c.ids,
                 ag_status_word(), deal);
   AG_LAUNCH_CHECK();
   if (c.pts != nullptr) {
