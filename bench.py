@@ -70,12 +70,13 @@ def algorithmic_bytes(kernel: str, sizes: dict) -> float:
         # one fused launch per edge set (3 per build), averaged.  Per edge: 8 B of ids read, 2 x 8 B of
         # endpoint coordinates gathered, 4 B of length and 8 B of direction written = 36 B.
         return 36.0 * sizes["e_total"] / 3.0
-    if kernel in ("ag_bin_count_kernel", "ag_bin_scatter_kernel"):
+    if kernel in ("ag_bin_count_kernel", "ag_bin_scatter_kernel", "ag_bin_records_kernel"):
         # binning calls of a build, averaged (the data nodes once -- the binning is kept and serves the encoder as
-        # sources and the decoder as targets -- and the hidden nodes once, as the decoder's sources): count reads
-        # coordinates and writes (cell, slot) per point; scatter reads all three and writes (unit vector, id) + id
+        # sources and the decoder as targets -- and the hidden nodes once, as the decoder's sources).  Per point:
+        # count reads the coordinates and writes the cell (12 B); scatter reads the cell and writes the id to its
+        # place (8 B); records reads the id and its coordinates and writes (unit vector, id) (28 B)
         n = (nd + nh) / 2.0
-        return (16.0 if kernel.endswith("count_kernel") else 36.0) * n
+        return {"ag_bin_count_kernel": 12.0, "ag_bin_scatter_kernel": 8.0, "ag_bin_records_kernel": 28.0}[kernel] * n
     if kernel == "ag_normalise_apply_kernel":  # the lengths of an edge set, read and written once (3 launches per build)
         return 8.0 * sizes["e_total"] / 3.0
     if kernel == "ag_ms_place_kernel":
