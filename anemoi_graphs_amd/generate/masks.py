@@ -19,40 +19,44 @@ class KNNAreaMaskBuilder:
     nodes (masks.py:23-99; same constructor, ``fit``, ``fit_coords``, ``get_mask``)."""
 
     def __init__(self, reference_node_name: str, margin_radius_km: float = 100, mask_attr_name: str | None = None):
-        assert isinstance(margin_radius_km, (int, float)), "The margin radius must be a number."
-        assert margin_radius_km > 0, "The margin radius must be positive."
+        if not isinstance(margin_radius_km, (int, float)):
+            raise AssertionError("The margin radius must be a number.")
+        if not margin_radius_km > 0:
+            raise AssertionError("The margin radius must be positive.")
+        self.reference_node_name, self.mask_attr_name = reference_node_name, mask_attr_name
         self.margin_radius_km = margin_radius_km
-        self.reference_node_name = reference_node_name
-        self.mask_attr_name = mask_attr_name
-        self._reference: torch.Tensor | None = None
+        self._reference: torch.Tensor | None = None  # device coordinates of the fitted nodes
+
+    @property
+    def _described(self) -> str:
+        """The reference nodes as the log names them: ``name`` or ``name (mask attribute)``."""
+        return self.reference_node_name + (f" ({self.mask_attr_name})" if self.mask_attr_name is not None else "")
 
     def get_reference_coords(self, graph) -> torch.Tensor:
-        """Coordinates of the reference nodes (masks.py:56-70)."""
-        assert (
-            self.reference_node_name in graph.node_types
-        ), f'Reference node "{self.reference_node_name}" not found in the graph.'
-        coords_rad = torch.as_tensor(graph[self.reference_node_name].x)
-        if self.mask_attr_name is not None:
-            assert (
-                self.mask_attr_name in graph[self.reference_node_name].node_attrs()
-            ), f'Mask attribute "{self.mask_attr_name}" not found in the reference nodes.'
-            mask = torch.as_tensor(graph[self.reference_node_name][self.mask_attr_name]).squeeze().bool()
-            coords_rad = coords_rad[mask.to(coords_rad.device)]
-        return coords_rad
+        """[n, 2] coordinates (radians) of the reference nodes, only those the mask attribute marks when one was
+        named (masks.py:56-70; a tensor on whichever device the graph keeps it, where the reference returns numpy)."""
+        if self.reference_node_name not in graph.node_types:
+            raise AssertionError(f'Reference node "{self.reference_node_name}" not found in the graph.')
+        nodes = graph[self.reference_node_name]
+        coords = torch.as_tensor(nodes.x)
+        if self.mask_attr_name is None:
+            return coords
+        if self.mask_attr_name not in nodes.node_attrs():
+            raise AssertionError(f'Mask attribute "{self.mask_attr_name}" not found in the reference nodes.')
+        keep = torch.as_tensor(nodes[self.mask_attr_name]).reshape(-1).to(device=coords.device, dtype=torch.bool)
+        return coords[keep]
 
     def fit_coords(self, coords_rad) -> None:
-        dev = ops.device_of(torch.as_tensor(coords_rad))
-        self._reference = ops.coords(np.asarray(coords_rad) if not isinstance(coords_rad, torch.Tensor) else coords_rad, dev)
+        """Take the reference nodes (masks.py:72-74): here they only move to the device; the search structure is
+        built by the query."""
+        points = coords_rad if isinstance(coords_rad, torch.Tensor) else np.asarray(coords_rad)
+        self._reference = ops.coords(points, ops.device_of(torch.as_tensor(points)))
 
     def fit(self, graph) -> None:
-        reference_mask_str = self.reference_node_name
-        if self.mask_attr_name is not None:
-            reference_mask_str += f" ({self.mask_attr_name})"
-        coords_rad = self.get_reference_coords(graph)
-        self.fit_coords(coords_rad)
-        LOGGER.info(
-            'Fitting %s with %d reference nodes from "%s".', self.__class__.__name__, len(coords_rad), reference_mask_str
-        )
+        """Take the reference nodes from a graph (masks.py:76-92)."""
+        self.fit_coords(self.get_reference_coords(graph))
+        LOGGER.info('Fitting %s with %d reference nodes from "%s".', type(self).__name__, self._reference.shape[0],
+                    self._described)
 
     def get_mask(self, coords_rad, density: float | None = None) -> torch.Tensor:
         """bool [N] device tensor: distance to the nearest reference node, in km, within the margin
