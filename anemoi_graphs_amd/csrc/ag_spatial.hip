@@ -93,9 +93,9 @@ __device__ __forceinline__ int ag_band_of_cell(const AgGrid& g, int c) {
 }
 
 // Which points a block takes: tiles of 256 * U consecutive points, U per thread (the thread's points are 256 apart,
-// every wavefront reads and writes whole lines).  U = 4 for large sets: the four loads of a thread, its four
-// counter updates and its four stores are in flight together, and a kernel that waits for memory most of its time
-// gets four times the bytes per wait.
+// every wavefront reads and writes whole lines).  U = 4 for sets of 2^22 points and more, 8 from 2^25: the U loads
+// of a thread, its U counter updates and its U stores are in flight together, and a kernel that waits for memory
+// most of its time gets U times the bytes per wait.
 // Blocks are handed to the eight dies in turn (block b to die b % 8), and every die has a second-level cache of
 // its own.  Points that follow each other in the caller's order (the rows of a grid) fall into the same cells, a
 // few points each: the record lines of those cells are completed by several blocks, and they are completed in ONE
@@ -108,7 +108,7 @@ struct AgTileDeal {
   int unroll;             // U: 1, 4 or 8
 };
 static AgTileDeal ag_tile_deal(int64_t n) {
-  const int unroll = n >= (int64_t(1) << 26) ? 8 : (n >= (int64_t(1) << 22) ? 4 : 1);
+  const int unroll = n >= (int64_t(1) << 25) ? 8 : (n >= (int64_t(1) << 22) ? 4 : 1);
   const int64_t per_tile = 256 * unroll, ntiles = (n + per_tile - 1) / per_tile;
   int chunk = 1;
   while (chunk < 1024 && int64_t(chunk) * 2 * 64 <= ntiles) chunk *= 2;  // (at least 8 rounds over the dies)

@@ -33,11 +33,29 @@ def device_of(*tensors: torch.Tensor) -> torch.device:
 # same tensors cross the link again and again: the data coordinates once per builder and attribute that reads them,
 # every edge list down to the host and up again for its attributes.  A host tensor that was uploaded, or that is the
 # host copy of a device result (``utils.to_host``), keeps its device twin here -- found again by the identity of the
-# tensor object and its version counter (any write torch knows of invalidates it), dropped when the host tensor
-# dies, and evicted oldest-first beyond a budget of device memory.
+# tensor object, its version counter (any write torch knows of invalidates it) and a fingerprint of its contents
+# (below), dropped when the host tensor dies, and evicted oldest-first beyond a budget of device memory.
 # ---------------------------------------------------------------------------------------------------
 _MIRROR_BUDGET = 4 << 30  # bytes of device memory the mirrors may hold
-_MIRRORS: dict = {}       # (id(host tensor), device index, dtype) -> (weak reference, version, device tensor)
+_MIRRORS: dict = {}       # (id(host tensor), device index, dtype) -> (weak reference, version, device tensor, fingerprint)
+
+
+def host_fingerprint(t: torch.Tensor):
+    """The bytes of about 500 evenly spaced elements of a contiguous host tensor (None for any other tensor).
+    torch counts the writes it makes itself; a write through a numpy array that shares the memory, or through
+    ``.data``, is invisible to that counter.  Such a write is noticed here when it changes one of the sampled
+    elements -- a grid rewritten in place does, an edit of a few nodes may not: ``forget_mirrors()`` after one."""
+    if t.device.type != "cpu" or not t.is_contiguous():
+        return None
+    flat = t.reshape(-1)
+    if flat.numel() == 0:
+        return b""
+    return flat[:: max(1, flat.numel() // 509)].contiguous().view(torch.uint8).numpy().tobytes()
+
+
+def forget_mirrors() -> None:
+    """Drop every device mirror of a host tensor (after writing to host tensors behind torch's back)."""
+    _MIRRORS.clear()
 
 
 def _mirror_drop(key) -> None:
@@ -49,6 +67,9 @@ def mirror_put(host: torch.Tensor, twin: torch.Tensor) -> None:
     nbytes = twin.numel() * twin.element_size()
     if nbytes > _MIRROR_BUDGET // 2 or twin.dtype != host.dtype or tuple(twin.shape) != tuple(host.shape):
         return
+    print_of = host_fingerprint(host)
+    if print_of is None:
+        return
     index = twin.device.index if twin.device.index is not None else torch.cuda.current_device()
     key = (id(host), index, twin.dtype)
     held = sum(v[2].numel() * v[2].element_size() for v in _MIRRORS.values())
@@ -57,13 +78,13 @@ def mirror_put(host: torch.Tensor, twin: torch.Tensor) -> None:
             break
         held -= _MIRRORS[old][2].numel() * _MIRRORS[old][2].element_size()
         del _MIRRORS[old]
-    _MIRRORS[key] = (weakref.ref(host, lambda _ref, key=key: _mirror_drop(key)), host._version, twin)
+    _MIRRORS[key] = (weakref.ref(host, lambda _ref, key=key: _mirror_drop(key)), host._version, twin, print_of)
 
 
 def _mirror_get(host: torch.Tensor, device: torch.device, dtype: torch.dtype):
     index = device.index if device.index is not None else torch.cuda.current_device()
     found = _MIRRORS.get((id(host), index, dtype))
-    if found is not None and found[0]() is host and found[1] == host._version:
+    if found is not None and found[0]() is host and found[1] == host._version and found[3] == host_fingerprint(host):
         return found[2]
     return None
 
@@ -230,15 +251,16 @@ class TensorStamp:
     """What a value derived from a tensor (a binning, a reference distance, a density) remembers of it: the tensor
     OBJECT -- held, so that its memory cannot be handed to another tensor while the value is kept -- and the
     version counter it had.  ``matches`` is true for that very object as long as no operation of torch has written
-    to it (a write through a numpy view or ``.data`` is not counted by torch and cannot be seen)."""
+    to it; for a host tensor also while its fingerprint stands (``host_fingerprint``: what torch cannot count, a
+    write through a numpy view or ``.data``, is noticed when it changes one of the sampled elements)."""
 
-    __slots__ = ("ref", "version")
+    __slots__ = ("ref", "version", "print_of")
 
     def __init__(self, t: torch.Tensor):
-        self.ref, self.version = t, t._version
+        self.ref, self.version, self.print_of = t, t._version, host_fingerprint(t)
 
     def matches(self, t) -> bool:
-        return self.ref is t and self.version == t._version
+        return self.ref is t and self.version == t._version and self.print_of == host_fingerprint(t)
 
 
 def tensor_key(t: torch.Tensor) -> TensorStamp:

@@ -256,3 +256,25 @@ def test_stores_of_the_stand_in_container_can_be_deleted():
     assert graph.edge_types == [] and graph.node_types == ["a"] and ("a", "to", "a") not in graph
     with pytest.raises(KeyError):
         del graph[("a", "to", "a")]
+
+
+def test_a_host_tensor_rewritten_behind_torchs_back_is_noticed():
+    """Device mirrors, kept binnings and cached distances are tied to the host tensor they came from: the object, its
+    version counter and a fingerprint of sampled elements -- a grid rewritten through the numpy array that shares
+    the tensor's memory leaves the first two alone."""
+    import numpy as np
+    import torch
+
+    from anemoi_graphs_amd import ops
+
+    arr = np.random.default_rng(0).random((5000, 2), dtype=np.float32)
+    x = torch.from_numpy(arr)
+    stamp = ops.tensor_key(x)
+    assert stamp.matches(x) and not stamp.matches(x.clone())
+    version = x._version
+    arr[:] = arr[::-1].copy()  # torch does not see this write
+    assert x._version == version
+    assert not stamp.matches(x)
+    assert ops.tensor_key(x).matches(x)
+    assert ops.host_fingerprint(x[:, 0]) is None  # (not contiguous: never mirrored)
+    assert ops.host_fingerprint(torch.empty(0)) == b""

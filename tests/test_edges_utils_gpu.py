@@ -134,3 +134,20 @@ def test_large_results_reach_the_host_whole(device):
             assert torch.equal(host, t.cpu())
     view = torch.arange(12_000_000, device=device, dtype=torch.float32).reshape(2, -1).t()  # not contiguous
     assert torch.equal(to_host(view), view.cpu())
+
+
+def test_device_mirror_follows_the_host_tensor(device):
+    """Coordinates given as a host tensor are uploaded once; a write torch counts, or one through the numpy array
+    behind the tensor, brings a fresh upload."""
+    arr = np.random.default_rng(1).random((4000, 2)).astype(np.float32)
+    x = torch.from_numpy(arr)
+    first = ops.coords(x, device)
+    assert ops.coords(x, device) is first and torch.equal(first.cpu(), x)
+    arr[:] = arr[::-1].copy()
+    second = ops.coords(x, device)
+    assert second is not first and torch.equal(second.cpu(), x)
+    x.mul_(0.5)
+    third = ops.coords(x, device)
+    assert third is not second and torch.equal(third.cpu(), x)
+    ops.forget_mirrors()
+    assert ops.coords(x, device) is not third
