@@ -1,4 +1,5 @@
-"""Where the host's time of a build goes: cProfile over builds of a tiny graph (negligible device work)."""
+"""Where the host's time of a build goes: cProfile over builds of a tiny graph (the device work is negligible).
+python tools/host_profile.py [octahedral N] [resolution] [overlap 0/1]"""
 import cProfile
 import pstats
 import sys
@@ -10,18 +11,20 @@ from anemoi_graphs_amd import grids, settings  # noqa: E402
 from anemoi_graphs_amd.distributed import ShardedGraphBuilder  # noqa: E402
 
 dev = torch.device("cuda", 0)
-data = torch.from_numpy(grids.octahedral(32)).to(dev)
-b = ShardedGraphBuilder(data, 3, overlap_processor=False)
+data = torch.from_numpy(grids.octahedral(int(sys.argv[1]) if len(sys.argv) > 1 else 32)).to(dev)
+res = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+overlap = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+b = ShardedGraphBuilder(data, res, overlap_processor=overlap)
 with settings.resident(True):
     for _ in range(20):
         b.build()
     torch.cuda.synchronize()
-    pr = cProfile.Profile()
-    pr.enable()
+    prof = cProfile.Profile()
+    prof.enable()
     for _ in range(200):
         b.build()
     torch.cuda.synchronize()
-    pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
-st.sort_stats("tottime").print_stats(30)
+    prof.disable()
+stats = pstats.Stats(prof)
+stats.sort_stats("tottime").print_stats(45)
+stats.sort_stats("cumulative").print_stats(130)
