@@ -5,6 +5,7 @@ The library is mandatory: there is no CPU or PyTorch fallback for any operation 
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch  # noqa: F401  -- must come first: the library then binds to the HIP runtime PyTorch loaded
 
@@ -21,6 +22,7 @@ SIGNATURES = {
     "ag_version": (c_int, []),
     "ag_status_take": (c_int, [ctypes.POINTER(c_int)]),
     "ag_debug_poison_scans": (c_int, [c_int]),
+    "ag_radius_group_order": (c_int, [c_int]),
     "ag_profile_enable": (c_int, [c_int]),
     "ag_profile_filter": (c_int, [ctypes.c_char_p]),
     "ag_profile_collect": (c_int, [ctypes.c_char_p, c_size_t]),
@@ -108,6 +110,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    if os.environ.get("AG_RADIUS_GROUPED") == "1":  # (for experiments: the cut-off query takes its targets in group order)
+        lib.ag_radius_group_order(1)
     _lib = lib
     return lib
 

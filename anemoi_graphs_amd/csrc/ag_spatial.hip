@@ -25,6 +25,8 @@
 #include <mutex>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ag_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -2844,12 +2846,16 @@ struct AgRadiusWs {
 // groups the index of an ordered query may hold (a third of the index lies beyond the ends of the shorter rows)
 static int64_t ag_radius_group_cap(int64_t nt) { return nt / 2 + 4096; }
 
-// Whether the count pass takes its targets in group order, and the shape of a group: only when the environment
-// says AG_RADIUS_GROUPED=1.  Measured on the O1280 -> r7 encoder, the order cuts the fabric traffic of the count
+// Whether the count pass takes its targets in group order, and the shape of a group: only when the caller has
+// asked for it (ag_radius_group_order).  Measured on the O1280 -> r7 encoder, the order cuts the fabric traffic of the count
 // kernel from 427 MB to 174 MB (7.7 x -> 3.1 x the bytes of the sources) and leaves its duration where it is
 // (0.099 -> 0.101 ms: the kernel waits for instruction issue, not for memory), while the three launches of the
 // counting sort of the targets add 0.04 ms to the query; 5e8 sources, 1e7 targets: 8.9 -> 8.2 ms for the kernel,
 // 1.7 ms for the sorting.  So the caller's order is what the library uses.
+static std::atomic<int> ag_radius_group_order_flag{0};
+
+extern "C" int ag_radius_group_order(int on) { return ag_radius_group_order_flag.exchange(on != 0 ? 1 : 0); }
+
 struct AgRadiusPlan {
   bool on = false;
   int B = 1, W = 1, nbg = 1, nch_max = 1;
@@ -2859,8 +2865,7 @@ struct AgRadiusPlan {
 
 static AgRadiusPlan ag_radius_plan(int64_t nt, int nb, double radius) {
   AgRadiusPlan p;
-  const char* env = getenv("AG_RADIUS_GROUPED");
-  if (env == nullptr || atoi(env) != 1 || nt < 1 || !(radius < AG_HALF_PI)) return p;
+  if (ag_radius_group_order_flag.load() == 0 || nt < 1 || !(radius < AG_HALF_PI)) return p;
   const double dlat = AG_PI / nb;
   p.rpad = radius + 1.0e-7 + 1.0e-6 * radius;
   const double ncells = 4.0 * nb * double(nb) / AG_PI;

@@ -115,12 +115,14 @@ def test_reference_distance_golden(device, golden):
 
 
 @pytest.fixture(params=["callers_order", "group_order"])
-def radius_path(request, monkeypatch):
-    """The two orders in which the count pass of the cut-off query takes its targets: the caller's, and sorted into
-    groups of neighbours (forced here whatever the sizes; the library reads the variable at every call).  Both must
-    give the same edge list."""
-    monkeypatch.setenv("AG_RADIUS_GROUPED", "0" if request.param == "callers_order" else "1")
-    return request.param
+def radius_path(request):
+    """The two orders in which the count pass of the cut-off query takes its targets: the caller's (the default), and
+    sorted into groups of neighbours (``ag_radius_group_order``).  Both must give the same edge list."""
+    from anemoi_graphs_amd import _lib
+
+    previous = _lib.load().ag_radius_group_order(0 if request.param == "callers_order" else 1)
+    yield request.param
+    _lib.load().ag_radius_group_order(previous)
 
 
 def _radius_case(src, tgt, radius, device):
