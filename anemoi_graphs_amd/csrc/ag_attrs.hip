@@ -39,6 +39,19 @@ __device__ __forceinline__ float ag_np_sin_f32(float x) {
   return s;
 }
 
+// The same sine for |x| < 0.78: there the quadrant of ag_np_sincos_f32 is 0 (|x| 2/pi < 0.4966 rounds to 0), its
+// reduced argument is x itself and its result the sine polynomial -- the same bits, without the reduction, the
+// cosine polynomial and the quadrant logic (also for a NaN and for either zero).
+#define AG_NP_SIN_SMALL 0.78f
+__device__ __forceinline__ float ag_np_sin_small_f32(float r) {
+  const float r2 = r * r;
+  float sp = __fmaf_rn(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
+  sp = __fmaf_rn(sp, r2, 0x1.11119ap-07f);
+  sp = __fmaf_rn(sp, r2, -0x1.555556p-03f);
+  sp = __fmaf_rn(sp, r2, 0.0f);
+  return __fmaf_rn(sp, r, r);
+}
+
 // 1/sqrt(x) for a normal, positive x: hardware seed (2^-23) + two Newton steps
 __device__ __forceinline__ double ag_rsqrt_f64(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -155,8 +168,17 @@ __device__ __forceinline__ void ag_attr_edge(float2 sp, const AgAttrRuns& R, int
     const float ct = R.cos_lat[r];
     const float dlat = tlat - sp.x;
     const float dlon = tlon - sp.y;
-    const float s0 = ag_np_sin_f32(dlat / 2.0f);
-    const float s1 = ag_np_sin_f32(dlon / 2.0f);
+    // the half differences of the edges of a wave are nearly always all small (an edge is short unless it crosses
+    // the date line): one wave-wide test picks the short form of the two sines
+    const float h0 = dlat / 2.0f, h1 = dlon / 2.0f;
+    float s0, s1;
+    if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(h0), fabsf(h1)) >= AG_NP_SIN_SMALL) == 0ull) {
+      s0 = ag_np_sin_small_f32(h0);
+      s1 = ag_np_sin_small_f32(h1);
+    } else {
+      s0 = ag_np_sin_f32(h0);
+      s1 = ag_np_sin_f32(h1);
+    }
     const float a = s0 * s0 + cs * ct * (s1 * s1);
     const float y = ag_sqrt_f32_rn(a), x = ag_sqrt_f32_rn(1.0f - a);
     *len = 2.0f * ag_atan2_pos_f32(y, x);
