@@ -882,8 +882,10 @@ __device__ __attribute__((noinline)) void ag_knn_scan_general(const AgKnnArgs* _
 
 // K = the number of neighbours when it is one of the small values instantiated below (the comparisons with it then
 // cost nothing), 0 = read it from the arguments.
+// (Short lists are held to 80 vector registers -- six waves per SIMD instead of five: O1280 -> r7 decoder 0.120 ->
+// 0.114 ms; at seven waves the registers spill and nothing is gained.)
 template <int CAP, int K>
-__global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK) void ag_knn_cell_kernel(AgKnnHot a) {
+__global__ __launch_bounds__(64 * AG_WAVES_PER_BLOCK, CAP <= 5 ? 6 : 1) void ag_knn_cell_kernel(AgKnnHot a) {
   if (ag_aborted(a.abort)) return;  // (a binning or a prefix sum upstream failed: see ag_aborted)
   __shared__ float4 tile_all[AG_WAVES_PER_BLOCK][AG_TILE];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
