@@ -32,20 +32,58 @@
 // ---------------------------------------------------------------------------------------------
 // grid construction
 // ---------------------------------------------------------------------------------------------
+// What a binning wants to know about the order of its points before it counts them (ag_bin_points): one block of
+// the band-table launch looks at 1024 pairs of consecutive points spread over the array and writes, to *order,
+// whether most pairs lie within a cell of each other (AG_ORDER_NEIGHBOURS: a grid stored row by row, a mesh sorted
+// by latitude) or not (AG_ORDER_SCATTERED: a spiral, a random order).  It also clears the second counter array.
+#define AG_ORDER_NEIGHBOURS 0
+#define AG_ORDER_SCATTERED 1
+struct AgBinProbe {
+  const float2* pts = nullptr;  // null: nothing to probe (a grid that only counts)
+  int64_t n = 0;
+  int* order = nullptr;
+  int* cursor = nullptr;  // [ncursor]: cleared
+  int64_t ncursor = 0;
+};
+
 // Block 0 computes the band tables; every block clears its share of the cell counters and of the
 // state words of the scan that turns the counters into cell starts.
 __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat, int mult, int* __restrict__ ncols,
                                                              int* __restrict__ off, double* __restrict__ win,
                                                              int* __restrict__ cell_count, int64_t ncount,
                                                              unsigned long long* __restrict__ scan_state,
-                                                             int64_t nstate, unsigned long long state_fill) {
+                                                             int64_t nstate, unsigned long long state_fill,
+                                                             AgBinProbe probe) {
   const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
   for (int64_t i = gtid; i < ncount; i += gsize) cell_count[i] = 0;
+  for (int64_t i = gtid; i < probe.ncursor; i += gsize) probe.cursor[i] = 0;
   // state of the scan of the counters: zero (anything else only from the test hook ag_debug_poison_scans)
   for (int64_t i = gtid; i < nstate; i += gsize) scan_state[i] = state_fill;
-  if (blockIdx.x != 0) return;
   __shared__ int partial[1024];
   const int tid = threadIdx.x;
+  if (probe.pts != nullptr && blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) {
+    // a pair (p, p + 1) per thread, at equal distances over the array; "within a cell": both differences below the
+    // band height
+    const int64_t pairs = probe.n - 1;
+    const int64_t samples = pairs < 1024 ? pairs : 1024;
+    bool close = false;
+    if (tid < samples) {
+      const int64_t p = (pairs / samples) * tid;
+      const float2 a = probe.pts[p], b = probe.pts[p + 1];
+      const float reach = static_cast<float>(dlat);
+      float dlon = fabsf(a.y - b.y);
+      dlon = fminf(dlon, fabsf(static_cast<float>(AG_TWO_PI) - dlon));
+      close = fabsf(a.x - b.x) <= reach && dlon * __cosf(a.x) <= reach;
+    }
+    if (tid == 0) partial[0] = 0;
+    __syncthreads();
+    const int in_wave = __popcll(__ballot(close));
+    if ((tid & 63) == 0 && in_wave) atomicAdd(&partial[0], in_wave);
+    __syncthreads();
+    if (tid == 0) *probe.order = (2 * int64_t(partial[0]) >= samples) ? AG_ORDER_NEIGHBOURS : AG_ORDER_SCATTERED;
+    __syncthreads();
+  }
+  if (blockIdx.x != 0) return;
   const int per = (nb + 1023) / 1024;
   const int b_begin = tid * per, b_end = min(nb, b_begin + per);
   const double rg = 0.98 * dlat;
@@ -142,79 +180,134 @@ __device__ __forceinline__ AgLaneRun ag_lane_run(int cell, int lane) {
   return r;
 }
 
-// The cell of every point, and how many points every cell holds: counter[1 + c] for cell c (the array is read one
-// entry further on, as the cell starts, once ag_bin_scatter_kernel has gone over it).
+// The cell of every point, and how many points every cell holds.  Points stored next to their neighbours: one
+// counter update per run, and nobody waits for the old value.  Points stored in a scattered order (every lane a run of
+// its own): the old value IS the point's slot in its cell, kept in slot_of, so that the scatter pass needs no second
+// round of updates -- with a point per update the updates are what a binning costs (510 million points of a spiral:
+// 23 ms per round).
 template <int U>
 __global__ __launch_bounds__(256) void ag_bin_count_kernel(AgGrid g, const float2* __restrict__ pts, int64_t n,
-                                                           int* __restrict__ cell_of, int* __restrict__ counter,
+                                                           int* __restrict__ cell_of, int* __restrict__ slot_of,
+                                                           int* __restrict__ counter, const int* __restrict__ order,
                                                            AgTileDeal deal) {
   const int lane = ag_lane();
+  const bool scattered = *order == AG_ORDER_SCATTERED;
   for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
     const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
     if (first - threadIdx.x >= n) continue;  // (the whole block)
     float2 p[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) p[u] = pts[min(first + u * 256, n - 1)];
+    if (!scattered) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = first + u * 256;
-      const bool on = i < n;
-      const int c = on ? ag_cell_of(g, static_cast<double>(p[u].x), static_cast<double>(p[u].y)) : -1;
-      const AgLaneRun run = ag_lane_run(c, lane);
-      if (run.head && on) atomicAdd(&counter[1 + c], run.length);  // (nobody waits for the old value)
-      if (on) cell_of[i] = c;
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = first + u * 256;
+        const bool on = i < n;
+        const int c = on ? ag_cell_of(g, static_cast<double>(p[u].x), static_cast<double>(p[u].y)) : -1;
+        const AgLaneRun run = ag_lane_run(c, lane);
+        if (run.head && on) atomicAdd(&counter[c], run.length);  // (nobody waits for the old value)
+        if (on) cell_of[i] = c;
+      }
+    } else {
+      int c[U], base[U], head_lane[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool on = first + u * 256 < n;
+        c[u] = on ? ag_cell_of(g, static_cast<double>(p[u].x), static_cast<double>(p[u].y)) : -1;
+        const AgLaneRun run = ag_lane_run(c[u], lane);
+        head_lane[u] = run.first;
+        base[u] = 0;
+        if (run.head && on) base[u] = atomicAdd(&counter[c[u]], run.length);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int start = __shfl(base[u], head_lane[u], 64);
+        const int64_t i = first + u * 256;
+        if (i < n) {
+          cell_of[i] = c[u];
+          slot_of[i] = start + (lane - head_lane[u]);
+        }
+      }
     }
   }
 }
 
-// The scan of the counters leaves the start of cell c in cursor[1 + c] and their total in cursor[1 + ncells]: every
-// point was counted once, so it is n.  The points then take their places: the head of a run moves the cursor of its
-// cell forward by the run, and the run's ids go where the cursor stood.  When every point is placed the cursor of
-// cell c stands at the start of cell c + 1: read from entry 0 (which nobody touched: zero) the array IS the cell
-// starts, entry ncells the total.
+// The scan of the counters leaves the start of cell c in cell_start[c] and their total in cell_start[ncells]: every
+// point was counted once, so it is n.  The points then take their places.  Stored next to their neighbours: the head
+// of a run moves the cursor of its cell (a second counter array, cleared with the first) forward by the run, and the
+// run's ids go to the cell's start plus where the cursor stood; only the ids are scattered (4 bytes a point: the lines
+// of a cell are completed by the blocks of several rows of the caller's grid, and lines that leave the cache half
+// written are what a scatter pays for), the 16-byte records are then written in their own order, whole lines at a
+// time, by ag_bin_records_kernel.  Stored in a scattered order: every point has its slot from the counting pass and
+// puts its id and its record there itself (a gather pass would meet the same scattered lines again).
 // A total other than n means that the scan gave up (state words that were not clear) and the starts cannot be
 // trusted -- some places would never be written, and the searches follow the ids they hold.  The binning is then
 // left EMPTY but sound: every cell without points, the ids (and with them the records) in the points' own order
 // (all initialised, all ids valid), and the library's status word set, which the host turns into an error at its
 // next synchronisation.
-// Only the ids are scattered (4 bytes a point: the lines of a cell are completed by the blocks of several rows of
-// the caller's grid, and lines that leave the cache half written are what a scatter pays for); the 16-byte records
-// are then written in their own order, whole lines at a time, by ag_bin_records_kernel.
 #define AG_STATUS_BINNING_FAILED 2
 template <int U>
-__global__ __launch_bounds__(256) void ag_bin_scatter_kernel(int64_t n, const int* __restrict__ cell_of,
-                                                             int* __restrict__ cursor, int64_t ncells,
-                                                             int* __restrict__ out_ids, int* __restrict__ status,
+__global__ __launch_bounds__(256) void ag_bin_scatter_kernel(const float2* __restrict__ pts, int64_t n,
+                                                             const int* __restrict__ cell_of,
+                                                             const int* __restrict__ slot_of, int* __restrict__ cursor,
+                                                             int* __restrict__ cell_start, int64_t ncells,
+                                                             float4* __restrict__ out_pts, int* __restrict__ out_ids,
+                                                             int* __restrict__ order, int* __restrict__ status,
                                                              AgTileDeal deal) {
-  if (cursor[1 + ncells] != static_cast<int>(n)) {  // (the same for every thread of the launch: nobody writes that word)
+  if (cell_start[ncells] != static_cast<int>(n)) {  // (the same for every thread of the launch: nobody writes that word)
     const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t c = gtid; c <= ncells; c += gsize) cursor[c] = 0;
+    for (int64_t c = gtid; c < ncells; c += gsize) cell_start[c] = 0;
     for (int64_t i = gtid; i < n; i += gsize) out_ids[i] = static_cast<int>(i);
     if (gtid == 0 && status != nullptr) *status = AG_STATUS_BINNING_FAILED;
-    return;
+    return;  // (the records follow the ids: ag_bin_records_kernel, whatever the order of the points)
   }
   const int lane = ag_lane();
+  const bool scattered = *order == AG_ORDER_SCATTERED;
   for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
     const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
     if (first - threadIdx.x >= n) continue;  // (the whole block)
-    int c[U], base[U], head_lane[U];
+    int c[U], place[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = first + u * 256;
       c[u] = i < n ? cell_of[i] : -1;
     }
+    if (!scattered) {
+      int head_lane[U], start[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const AgLaneRun run = ag_lane_run(c[u], lane);
-      head_lane[u] = run.first;
-      base[u] = 0;
-      if (run.head && c[u] >= 0) base[u] = atomicAdd(&cursor[1 + c[u]], run.length);
-    }
+      for (int u = 0; u < U; ++u) {
+        const AgLaneRun run = ag_lane_run(c[u], lane);
+        head_lane[u] = run.first;
+        place[u] = 0;
+        start[u] = c[u] >= 0 ? cell_start[c[u]] : 0;
+        if (run.head && c[u] >= 0) place[u] = atomicAdd(&cursor[c[u]], run.length);
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int place = __shfl(base[u], head_lane[u], 64) + (lane - head_lane[u]);
-      const int64_t i = first + u * 256;
-      if (i < n) out_ids[place] = static_cast<int>(i);
+      for (int u = 0; u < U; ++u) {
+        place[u] = start[u] + __shfl(place[u], head_lane[u], 64) + (lane - head_lane[u]);
+        const int64_t i = first + u * 256;
+        if (i < n) out_ids[place[u]] = static_cast<int>(i);
+      }
+    } else {
+      float2 p[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // (lanes past the end read the last point again and write nothing)
+        const int64_t i = min(first + u * 256, n - 1);
+        place[u] = slot_of[i];
+        if (out_pts != nullptr) p[u] = pts[i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) place[u] += c[u] >= 0 ? cell_start[c[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = first + u * 256;
+        if (i >= n) continue;
+        out_ids[place[u]] = static_cast<int>(i);
+        if (out_pts != nullptr) {
+          const float3 v = ag_unit_vec(p[u].x, p[u].y);
+          out_pts[place[u]] = make_float4(v.x, v.y, v.z, __int_as_float(static_cast<int>(i)));
+        }
+      }
     }
   }
 }
@@ -225,7 +318,12 @@ __global__ __launch_bounds__(256) void ag_bin_scatter_kernel(int64_t n, const in
 template <int U>
 __global__ __launch_bounds__(256) void ag_bin_records_kernel(const float2* __restrict__ pts, int64_t n,
                                                              const int* __restrict__ ids, float4* __restrict__ out_pts,
+                                                             const int* __restrict__ order,
+                                                             const int* __restrict__ cell_start, int64_t ncells,
                                                              AgTileDeal deal) {
+  // (points in a scattered order: the scatter pass wrote the records too -- unless the binning failed, and the ids
+  // it left are the identity)
+  if (*order == AG_ORDER_SCATTERED && cell_start[ncells] == static_cast<int>(n)) return;
   for (int64_t vb = blockIdx.x; vb < deal.ntiles_padded; vb += gridDim.x) {
     const int64_t first = ag_dealt_tile(vb, deal.chunk) * (256 * U) + threadIdx.x;
     if (first - threadIdx.x >= n) continue;  // (the whole block)
@@ -276,7 +374,7 @@ static int64_t ag_grid_cells_ub(int nb, int mult = 1) {
 }
 
 struct AgBinCarve {
-  int *ncols, *off, *cell_start, *cell_of, *ids;
+  int *ncols, *off, *cell_start, *cursor, *order, *cell_of, *slot_of, *ids;
   double* win;
   float4* pts;
   unsigned long long* scan_state;
@@ -288,10 +386,11 @@ static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool
   c->ncols = ws.take<int>(nb_reserve);
   c->off = ws.take<int>(nb_reserve + 1);
   c->win = ws.take<double>(nb_reserve);
-  // (entry 1, where the counters and the scan begin, on a 16-byte boundary: the scan moves 16-byte pieces then)
-  int* const counters = ws.take<int>(cells + 4);
-  c->cell_start = counters ? counters + 3 : nullptr;
+  c->cell_start = ws.take<int>(cells);
+  c->cursor = ws.take<int>(cells);
+  c->order = ws.take<int>(4);
   c->cell_of = ws.take<int>(n);
+  c->slot_of = ws.take<int>(n);
   c->ids = ws.take<int>(n);
   c->scan_words = static_cast<int64_t>(ag_chained_scan_state_words_i32(cells));
   c->scan_state = ws.take<unsigned long long>(c->scan_words);
@@ -321,9 +420,16 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   if (out == nullptr) return AG_OK;  // sizing pass
   ag_bin_describe(c, n, nb, mult, out);
   const int64_t ncells_ub = out->ncells_ub;
+  AgBinProbe probe;
+  probe.pts = reinterpret_cast<const float2*>(d_pts);
+  probe.n = n;
+  probe.order = c.order;
+  probe.cursor = c.cursor;
+  probe.ncursor = ncells_ub + 1;
   AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(ncells_ub + 1, 4096, 256)), dim3(1024), stream,
-            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 2, c.scan_state, c.scan_words,
-            ag_debug_scans_poisoned() ? 0x40000000ull : 0ull);  // (poisoned: every tile draws a ticket beyond the last tile)
+            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1, c.scan_state, c.scan_words,
+            ag_debug_scans_poisoned() ? 0x40000000ull : 0ull,  // (poisoned: every tile draws a ticket beyond the last tile)
+            probe);
   AG_LAUNCH_CHECK();
   int rc = AG_OK;
   const AgTileDeal deal = ag_tile_deal(n);
@@ -339,16 +445,16 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
     }                                                                                           \
   } while (0)
   AG_BIN_LAUNCH("ag_bin_count_kernel", ag_bin_count_kernel, out->grid, reinterpret_cast<const float2*>(d_pts), n,
-                c.cell_of, c.cell_start, deal);
+                c.cell_of, c.slot_of, c.cell_start, c.order, deal);
   AG_LAUNCH_CHECK();
-  rc = ag_chained_scan_i32(c.cell_start + 1, c.cell_start + 1, ncells_ub, c.scan_state, stream);  // total -> [1 + ncells_ub]
+  rc = ag_chained_scan_i32(c.cell_start, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> [ncells_ub]
   if (rc) return rc;
-  AG_BIN_LAUNCH("ag_bin_scatter_kernel", ag_bin_scatter_kernel, n, c.cell_of, c.cell_start, ncells_ub, c.ids,
-                ag_status_word(), deal);
+  AG_BIN_LAUNCH("ag_bin_scatter_kernel", ag_bin_scatter_kernel, reinterpret_cast<const float2*>(d_pts), n, c.cell_of,
+                c.slot_of, c.cursor, c.cell_start, ncells_ub, c.pts, c.ids, c.order, ag_status_word(), deal);
   AG_LAUNCH_CHECK();
   if (c.pts != nullptr) {
     AG_BIN_LAUNCH("ag_bin_records_kernel", ag_bin_records_kernel, reinterpret_cast<const float2*>(d_pts), n, c.ids, c.pts,
-                  deal);
+                  c.order, c.cell_start, ncells_ub, deal);
     AG_LAUNCH_CHECK();
   }
 #undef AG_BIN_LAUNCH
@@ -1860,7 +1966,7 @@ static int ag_knn_run(const float* d_src, int64_t ns, const float* d_tgt, int64_
     const int64_t occ_cells = ag_grid_cells_ub(nb_occ);
     AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(occ_cells + 1, 4096, 256)), dim3(1024), stream,
               nb_occ, a.occ_grid.dlat, 1, w.occ_ncols, w.occ_off, w.occ_win, w.occ_count, occ_cells + 1,
-              static_cast<unsigned long long*>(nullptr), int64_t(0), 0ull);
+              static_cast<unsigned long long*>(nullptr), int64_t(0), 0ull, AgBinProbe());
     AG_LAUNCH_CHECK();
     AG_KERNEL("ag_occupancy_count_kernel", ag_occupancy_count_kernel, dim3(ag_blocks(ns, 256, 16384)), dim3(256), stream,
               a.occ_grid, a.src, ns, w.occ_count);

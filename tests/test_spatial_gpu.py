@@ -514,3 +514,35 @@ def test_radius_rows_of_exact_lengths_are_sorted(device, n, radius_path):
         assert np.array_equal(e, h.canonical(e)), (n, order)
         want = np.sort(np.flatnonzero(np.isin(perm, np.arange(len(far), len(far) + n))))
         assert np.array_equal(e[0].reshape(40, n), np.broadcast_to(want, (40, n)))
+
+
+def test_searches_do_not_depend_on_the_order_of_the_nodes(device):
+    """A grid stored row by row (neighbours next to each other: the binning counts runs of points and places them with
+    a cursor per cell) and the same nodes shuffled (a scattered order: every point keeps the slot its counter update
+    returned) give the same neighbours and the same cut-off edges, id for id."""
+    data = grids.octahedral(160)  # 108,160 nodes, rows of constant latitude
+    # (nudged: on the exact grid a node's left and right neighbours tie, and ties go to the lower id -- which the
+    # shuffle changes)
+    data = (data + np.random.default_rng(4).uniform(-2e-4, 2e-4, data.shape)).astype(np.float32)
+    data[:, 0] = np.clip(data[:, 0], -np.pi / 2, np.pi / 2)
+    data[:, 1] = np.mod(data[:, 1], np.float32(2 * np.pi))
+    hidden = grids.fibonacci_sphere(2562)
+    perm = np.random.default_rng(5).permutation(len(data))
+    shuffled = data[perm]
+    d0, d1 = torch.from_numpy(data).to(device), torch.from_numpy(shuffled).to(device)
+    hd = torch.from_numpy(hidden).to(device)
+    radius = rp.cutoff_radius(hidden, 0.6)
+    # the grid as sources of a cut-off query
+    e0 = ops.radius_edges(d0, hd, radius).cpu().numpy()
+    e1 = ops.radius_edges(d1, hd, radius).cpu().numpy()
+    e1 = np.stack([perm[e1[0]], e1[1]])
+    assert np.array_equal(h.canonical(e0), h.canonical(e1)) and e0.shape[1] > 0
+    # the grid as sources of a k-NN query, with itself as the targets
+    n0 = ops.knn(d0, d0[:5000], 4).cpu().numpy()
+    n1 = ops.knn(d1, d0[:5000], 4).cpu().numpy()
+    assert np.array_equal(np.sort(n0, axis=1), np.sort(perm[n1], axis=1))
+    # and against the oracle once
+    from oracle import compare as cmp
+
+    want = cmp.knn_rows(rp.knn_edges(data, data[:5000], 4), 5000, 4)
+    assert np.array_equal(np.sort(n0, axis=1), np.sort(want, axis=1))

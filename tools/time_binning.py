@@ -1,5 +1,6 @@
 """Developer tool: the binning of a node set alone, with the device time of every kernel (HIP events).
-python tools/time_binning.py [grid | stretched:<nodes>] [mesh resolution, for the cell size] [repeats]"""
+python tools/time_binning.py [grid | stretched:<nodes> | spiral:<nodes> | random:<nodes>] [mesh resolution, for the cell
+size] [repeats]        (spiral: a Fibonacci spiral, consecutive nodes far apart; random: uniform, in random order)"""
 import sys
 import time
 from pathlib import Path
@@ -17,6 +18,16 @@ if name.startswith("stretched:"):
     n = float(name.split(":")[1])
     fine = 1.0 * (5.0e8 / n) ** 0.5
     data = grids.stretched_for_nodes(n, 9.0 * fine, fine).generate(device=dev)
+elif name.startswith("spiral:"):
+    from tools.capacity_check import fibonacci_on_device
+
+    data = fibonacci_on_device(int(float(name.split(":")[1])), dev)
+elif name.startswith("random:"):
+    n = int(float(name.split(":")[1]))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    data = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    data[:, 0] = torch.asin(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 2.0 - 1.0).to(torch.float32)
+    data[:, 1] = (torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 6.283185307179586).to(torch.float32)
 else:
     data = torch.from_numpy(grids.named(name)).to(dev)
 hidden = ops.icosphere(res, dev)[2]
