@@ -35,15 +35,13 @@
 // What a binning wants to know about the order of its points before it counts them (ag_bin_points): one block of
 // the band-table launch looks at 1024 pairs of consecutive points spread over the array and writes, to *order,
 // whether most pairs lie within a cell of each other (AG_ORDER_NEIGHBOURS: a grid stored row by row, a mesh sorted
-// by latitude) or not (AG_ORDER_SCATTERED: a spiral, a random order).  It also clears the second counter array.
+// by latitude) or not (AG_ORDER_SCATTERED: a spiral, a random order).
 #define AG_ORDER_NEIGHBOURS 0
 #define AG_ORDER_SCATTERED 1
 struct AgBinProbe {
   const float2* pts = nullptr;  // null: nothing to probe (a grid that only counts)
   int64_t n = 0;
   int* order = nullptr;
-  int* cursor = nullptr;  // [ncursor]: cleared
-  int64_t ncursor = 0;
 };
 
 // Block 0 computes the band tables; every block clears its share of the cell counters and of the
@@ -56,7 +54,6 @@ __global__ __launch_bounds__(1024) void ag_band_table_kernel(int nb, double dlat
                                                              AgBinProbe probe) {
   const int64_t gtid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x, gsize = int64_t(gridDim.x) * blockDim.x;
   for (int64_t i = gtid; i < ncount; i += gsize) cell_count[i] = 0;
-  for (int64_t i = gtid; i < probe.ncursor; i += gsize) probe.cursor[i] = 0;
   // state of the scan of the counters: zero (anything else only from the test hook ag_debug_poison_scans)
   for (int64_t i = gtid; i < nstate; i += gsize) scan_state[i] = state_fill;
   __shared__ int partial[1024];
@@ -234,8 +231,9 @@ __global__ __launch_bounds__(256) void ag_bin_count_kernel(AgGrid g, const float
 
 // The scan of the counters leaves the start of cell c in cell_start[c] and their total in cell_start[ncells]: every
 // point was counted once, so it is n.  The points then take their places.  Stored next to their neighbours: the head
-// of a run moves the cursor of its cell (a second counter array, cleared with the first) forward by the run, and the
-// run's ids go to the cell's start plus where the cursor stood; only the ids are scattered (4 bytes a point: the lines
+// of a run takes the run's places off the END of what is left of its cell -- the counters, which the scan read but
+// did not change, are counted down, so nothing has to be cleared for this pass -- and the run's ids go to the cell's
+// start plus what was left minus the run; only the ids are scattered (4 bytes a point: the lines
 // of a cell are completed by the blocks of several rows of the caller's grid, and lines that leave the cache half
 // written are what a scatter pays for), the 16-byte records are then written in their own order, whole lines at a
 // time, by ag_bin_records_kernel.  Stored in a scattered order: every point has its slot from the counting pass and
@@ -249,7 +247,7 @@ __global__ __launch_bounds__(256) void ag_bin_count_kernel(AgGrid g, const float
 template <int U>
 __global__ __launch_bounds__(256) void ag_bin_scatter_kernel(const float2* __restrict__ pts, int64_t n,
                                                              const int* __restrict__ cell_of,
-                                                             const int* __restrict__ slot_of, int* __restrict__ cursor,
+                                                             const int* __restrict__ slot_of, int* __restrict__ left,
                                                              int* __restrict__ cell_start, int64_t ncells,
                                                              float4* __restrict__ out_pts, int* __restrict__ out_ids,
                                                              int* __restrict__ order, int* __restrict__ status,
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(256) void ag_bin_scatter_kernel(const float2* __res
         head_lane[u] = run.first;
         place[u] = 0;
         start[u] = c[u] >= 0 ? cell_start[c[u]] : 0;
-        if (run.head && c[u] >= 0) place[u] = atomicAdd(&cursor[c[u]], run.length);
+        if (run.head && c[u] >= 0) place[u] = atomicSub(&left[c[u]], run.length) - run.length;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -374,7 +372,7 @@ static int64_t ag_grid_cells_ub(int nb, int mult = 1) {
 }
 
 struct AgBinCarve {
-  int *ncols, *off, *cell_start, *cursor, *order, *cell_of, *slot_of, *ids;
+  int *ncols, *off, *count, *cell_start, *order, *cell_of, *slot_of, *ids;
   double* win;
   float4* pts;
   unsigned long long* scan_state;
@@ -386,8 +384,8 @@ static void ag_bin_carve(AgCarver& ws, int64_t n, int nb_reserve, int mult, bool
   c->ncols = ws.take<int>(nb_reserve);
   c->off = ws.take<int>(nb_reserve + 1);
   c->win = ws.take<double>(nb_reserve);
+  c->count = ws.take<int>(cells);
   c->cell_start = ws.take<int>(cells);
-  c->cursor = ws.take<int>(cells);
   c->order = ws.take<int>(4);
   c->cell_of = ws.take<int>(n);
   c->slot_of = ws.take<int>(n);
@@ -424,10 +422,8 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
   probe.pts = reinterpret_cast<const float2*>(d_pts);
   probe.n = n;
   probe.order = c.order;
-  probe.cursor = c.cursor;
-  probe.ncursor = ncells_ub + 1;
   AG_KERNEL("ag_band_table_kernel", ag_band_table_kernel, dim3(ag_blocks(ncells_ub + 1, 4096, 256)), dim3(1024), stream,
-            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.cell_start, ncells_ub + 1, c.scan_state, c.scan_words,
+            nb, out->grid.dlat, mult, c.ncols, c.off, c.win, c.count, ncells_ub + 1, c.scan_state, c.scan_words,
             ag_debug_scans_poisoned() ? 0x40000000ull : 0ull,  // (poisoned: every tile draws a ticket beyond the last tile)
             probe);
   AG_LAUNCH_CHECK();
@@ -445,12 +441,12 @@ int ag_bin_points(AgCarver& ws, const float* d_pts, int64_t n, int nb, int nb_re
     }                                                                                           \
   } while (0)
   AG_BIN_LAUNCH("ag_bin_count_kernel", ag_bin_count_kernel, out->grid, reinterpret_cast<const float2*>(d_pts), n,
-                c.cell_of, c.slot_of, c.cell_start, c.order, deal);
+                c.cell_of, c.slot_of, c.count, c.order, deal);
   AG_LAUNCH_CHECK();
-  rc = ag_chained_scan_i32(c.cell_start, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> [ncells_ub]
+  rc = ag_chained_scan_i32(c.count, c.cell_start, ncells_ub, c.scan_state, stream);  // total -> cell_start[ncells_ub]
   if (rc) return rc;
   AG_BIN_LAUNCH("ag_bin_scatter_kernel", ag_bin_scatter_kernel, reinterpret_cast<const float2*>(d_pts), n, c.cell_of,
-                c.slot_of, c.cursor, c.cell_start, ncells_ub, c.pts, c.ids, c.order, ag_status_word(), deal);
+                c.slot_of, c.count, c.cell_start, ncells_ub, c.pts, c.ids, c.order, ag_status_word(), deal);
   AG_LAUNCH_CHECK();
   if (c.pts != nullptr) {
     AG_BIN_LAUNCH("ag_bin_records_kernel", ag_bin_records_kernel, reinterpret_cast<const float2*>(d_pts), n, c.ids, c.pts,
