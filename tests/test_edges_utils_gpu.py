@@ -119,8 +119,8 @@ def test_single_launch_scan_and_its_bounded_wait(device):
 
 
 def test_large_results_reach_the_host_whole(device):
-    """Results of tens of megabytes travel as several pieces on streams of their own: the host tensor holds every
-    element, also when the work that makes the tensor was queued just before the copy."""
+    """Results of tens of megabytes go to page-locked host memory with a copy queued behind the work that makes the
+    tensor: the host tensor holds every element when the call returns."""
     from anemoi_graphs_amd.utils import to_host
 
     torch.cuda.set_device(device)
