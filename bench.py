@@ -311,6 +311,10 @@ def run(args) -> int:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: the host-side (gloo) group that carries the edge counts talks over the loopback interface,
+            # whatever the machine's host name resolves to (or fails to)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
 
